@@ -1,0 +1,198 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+Vectorised numpy restatement of one ADER-DG step (space-time predictor Picard
+loop, time averages, volume integral, face extrapolation, Rusanov Riemann
+solve, surface corrector) on a periodic regular Cartesian grid, d in {1,2,3}.
+
+Reference anchor: none -- /root/reference holds no ADER-DG code (SURVEY.md
+F2).  Follows SURVEY.md Appendix A.2-A.4.  "parity unpinned" against the
+reference; pinned by the KATs of SURVEY.md A.5 (tests/test_aderdg_kat.py).
+The point-wise Euler terms follow the arithmetic of the reference's
+`Unit test/Functions.cpp:9-62` (gamma = 1.4, conservative variables), extended
+to a 3-component momentum (rho, m0, m1, m2, E) and without the stray
+`F[3]` overwrite of its 3-D branch.
+
+Array layout: u[grid (d axes), node (d axes), var]; axis 0 of the grid/node
+index is the reference's `i` (normal = 0), the slowest one.
+"""
+import numpy as np
+from .dg_operators import operators
+
+GAMMA = 1.4
+
+
+class Advection:
+    """Linear advection of m variables with velocity a (length d)."""
+
+    def __init__(self, a, m=1):
+        self.a = np.asarray(a, dtype=float)
+        self.m = m
+
+    def flux(self, q, d):
+        return self.a[d] * q
+
+    def maxeig(self, q, d):
+        return np.full(q.shape[:-1], abs(self.a[d]))
+
+
+class Euler:
+    """Compressible Euler, 5 variables (rho, m0, m1, m2, E), gamma = 1.4."""
+    m = 5
+
+    def flux(self, q, d):
+        rho = q[..., 0]
+        irho = 1.0 / rho
+        e = q[..., 4]
+        p = (GAMMA - 1) * (e - 0.5 * irho * (q[..., 1] * q[..., 1] + q[..., 2] * q[..., 2] + q[..., 3] * q[..., 3]))
+        coeff = irho * q[..., d + 1]
+        F = np.empty_like(q)
+        F[..., 0] = coeff * rho
+        F[..., 1] = coeff * q[..., 1]
+        F[..., 2] = coeff * q[..., 2]
+        F[..., 3] = coeff * q[..., 3]
+        F[..., 4] = coeff * e + coeff * p
+        F[..., d + 1] += p
+        return F
+
+    def maxeig(self, q, d):
+        irho = 1.0 / np.abs(q[..., 0])
+        e = q[..., 4]
+        p = (GAMMA - 1) * (e - 0.5 * irho * (q[..., 1] * q[..., 1] + q[..., 2] * q[..., 2] + q[..., 3] * q[..., 3]))
+        c = np.sqrt(GAMMA * np.abs(p) * irho)
+        un = q[..., d + 1] * irho
+        return np.maximum(np.abs(un - c), np.abs(un + c))
+
+
+def _apply(M, A, axis):
+    """out[.., i, ..] = sum_j M[i][j] A[.., j, ..] along `axis`."""
+    return np.moveaxis(np.tensordot(M, A, axes=([1], [axis])), 0, axis)
+
+
+def _dim(u):
+    return (u.ndim - 1) // 2
+
+
+def predictor(u, dt, dx, ops, pde, n_it=None):
+    """Space-time predictor q[grid, l, node, var] (A.2)."""
+    d = _dim(u)
+    N = ops['N']
+    if n_it is None:
+        n_it = N
+    D, iK1, F0, w = ops['D'], ops['iK1'], ops['F0'], ops['w']
+    ue = np.expand_dims(u, d)                      # time axis at position d
+    q = np.repeat(ue, N, axis=d)
+    tshape = [1] * q.ndim
+    tshape[d] = N
+    for _ in range(n_it):
+        S = np.zeros_like(q)
+        for a in range(d):
+            S += _apply(D, pde.flux(q, a), d + 1 + a) / dx[a]
+        R = F0.reshape(tshape) * ue - dt * w.reshape(tshape) * S
+        q = _apply(iK1, R, d)
+    return q
+
+
+def time_averages(q, ops, pde):
+    d = (q.ndim - 2) // 2
+    w = ops['w']
+    qbar = np.tensordot(w, q, axes=([0], [d]))
+    Fbar = [np.tensordot(w, pde.flux(q, a), axes=([0], [d])) for a in range(d)]
+    return qbar, Fbar
+
+
+def volume(u, Fbar, dt, dx, ops):
+    d = _dim(u)
+    N = ops['N']
+    Kxi, w = ops['Kxi'], ops['w']
+    us = u.copy()
+    for a in range(d):
+        sh = [1] * u.ndim
+        sh[d + a] = N
+        us += dt / dx[a] * _apply(Kxi, Fbar[a], d + a) / w.reshape(sh)
+    return us
+
+
+def traces(qbar, Fbar, ops):
+    """Return lists (per direction a) of qL,qR,FL,FR with the node axis a removed."""
+    d = _dim(qbar)
+    out = []
+    for a in range(d):
+        ax = d + a
+        qL = np.tensordot(ops['phiL'], qbar, axes=([0], [ax]))
+        qR = np.tensordot(ops['phiR'], qbar, axes=([0], [ax]))
+        FL = np.tensordot(ops['phiL'], Fbar[a], axes=([0], [ax]))
+        FR = np.tensordot(ops['phiR'], Fbar[a], axes=([0], [ax]))
+        # tensordot puts the contracted result's remaining axes in order -> axis removed
+        out.append((qL, qR, FL, FR))
+    return out
+
+
+def riemann(tr, pde, d):
+    """Rusanov flux at the RIGHT face of every cell, per direction (periodic).
+
+    Fstar[a][grid..., transverse nodes..., var] is the flux between cell c (its
+    R trace) and cell c+e_a (its L trace); s = max over the face's nodes (A.4).
+    """
+    Fs = []
+    for a in range(d):
+        qL, qR, FL, FR = tr[a]
+        qm, Fm = qR, FR                                   # "-" side: this cell's R
+        qp, Fp = np.roll(qL, -1, axis=a), np.roll(FL, -1, axis=a)   # "+": right neighbour's L
+        lam = np.maximum(pde.maxeig(qm, a), pde.maxeig(qp, a))
+        if d > 1:
+            s = lam.max(axis=tuple(range(d, d + d - 1)), keepdims=True)
+        else:
+            s = lam
+        Fs.append(0.5 * (Fm + Fp) - 0.5 * s[..., None] * (qp - qm))
+    return Fs
+
+
+def corrector(us, Fstar, dt, dx, ops):
+    d = _dim(us)
+    N = ops['N']
+    w, phiL, phiR = ops['w'], ops['phiL'], ops['phiR']
+    un = us.copy()
+    for a in range(d):
+        FR = np.expand_dims(Fstar[a], d + a)                      # right face of cell
+        FLft = np.expand_dims(np.roll(Fstar[a], 1, axis=a), d + a)  # left face = left neighbour's right face
+        sh = [1] * us.ndim
+        sh[d + a] = N
+        un -= dt / dx[a] * (phiR.reshape(sh) * FR - phiL.reshape(sh) * FLft) / w.reshape(sh)
+    return un
+
+
+def step(u, dt, dx, ops, pde, n_it=None, stages=False):
+    d = _dim(u)
+    q = predictor(u, dt, dx, ops, pde, n_it)
+    qbar, Fbar = time_averages(q, ops, pde)
+    us = volume(u, Fbar, dt, dx, ops)
+    tr = traces(qbar, Fbar, ops)
+    Fs = riemann(tr, pde, d)
+    un = corrector(us, Fs, dt, dx, ops)
+    if stages:
+        return dict(q=q, qbar=qbar, Fbar=Fbar, ustar=us, traces=tr, Fstar=Fs, unew=un)
+    return un
+
+
+def step_single_stage(u, dt, dx, ops, pde):
+    """cfg 1 variant: volume + Riemann + corrector only (qbar := u, Fbar := f(u))."""
+    d = _dim(u)
+    Fbar = [pde.flux(u, a) for a in range(d)]
+    us = volume(u, Fbar, dt, dx, ops)
+    tr = traces(u, Fbar, ops)
+    Fs = riemann(tr, pde, d)
+    return corrector(us, Fs, dt, dx, ops)
+
+
+def node_coords(grid, N, ops):
+    """Physical coordinates on [0,1]^d: list of arrays broadcastable to grid+nodes."""
+    d = len(grid)
+    xs = []
+    for a in range(d):
+        h = 1.0 / grid[a]
+        x = (np.arange(grid[a])[:, None] + ops['xi'][None, :]) * h      # [cells, N]
+        sh = [1] * (2 * d)
+        sh[a] = grid[a]
+        sh[d + a] = N
+        xs.append(x.reshape(sh))
+    return xs
