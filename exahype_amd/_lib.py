@@ -1,0 +1,89 @@
+"""ctypes binding of libexahype_hip.so (include/exahype_hip.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc, and
+if that fails -- or a call reports an error -- an exception is raised.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libexahype_hip.so")
+
+PDE_EULER_REF2D, PDE_EULER, PDE_ADVECTION = 0, 1, 2
+FV_FAITHFUL, FV_RUSANOV = 0, 1
+
+# every symbol include/exahype_hip.h declares: (restype, argtypes)
+_vp, _dp, _lp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long)
+SIGNATURES = {
+    "exa_version": (C.c_int, []),
+    "exa_last_error": (C.c_char_p, []),
+    "exa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "exa_pde_eval_device": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _vp, _vp, _vp, _vp]),
+    "exa_fv_plan_create": (C.c_int, [C.c_int] * 7 + [C.c_long, C.c_int, C.POINTER(_vp)]),
+    "exa_fv_plan_destroy": (C.c_int, [_vp]),
+    "exa_fv_q_count": (C.c_long, [_vp]),
+    "exa_fv_time_step_host": (C.c_int, [_vp, _vp, C.c_double, C.c_double]),
+    "exa_fv_time_step_device": (C.c_int, [_vp, _vp, C.c_double, C.c_double, _vp]),
+    "exa_dg_plan_create": (C.c_int, [C.c_int] * 6 + [_lp, C.POINTER(_vp)]),
+    "exa_dg_plan_destroy": (C.c_int, [_vp]),
+    "exa_dg_dof_count": (C.c_long, [_vp]),
+    "exa_dg_trace_count": (C.c_long, [_vp]),
+    "exa_dg_face_count": (C.c_long, [_vp, C.c_int]),
+    "exa_dg_operators": (C.c_int, [_vp] + [_vp] * 7),
+    "exa_dg_work": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "exa_dg_predictor_volume": (C.c_int, [_vp, _vp, _vp, C.c_double, _dp, _vp]),
+    "exa_dg_predictor_volume_box": (C.c_int, [_vp, _vp, _vp, _lp, _lp, C.c_double, _dp, _vp]),
+    "exa_dg_riemann_corrector": (C.c_int, [_vp, _vp, _vp, C.POINTER(_vp), _lp, _lp, C.c_double, _dp, _vp]),
+    "exa_dg_pack_face": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "exa_dg_max_eigenvalue": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "exa_dg_step_periodic": (C.c_int, [_vp, _vp, _vp, C.c_double, _dp, C.c_int, _vp]),
+    "exa_dg_step_host": (C.c_int, [_vp, _vp, C.c_double, _dp, C.c_int]),
+}
+
+
+class ExaHypeHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Load (building first if needed) the HIP library; raises if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise ExaHypeHipError(f"{LIB_PATH} is missing (run `python -m exahype_amd.build`); there is no CPU fallback")
+        from . import build as _build
+        _build.build()
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise ExaHypeHipError(f"cannot load {LIB_PATH}: {e}; there is no CPU fallback") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ExaHypeHipError("libexahype_hip error %d: %s" % (rc, load().exa_last_error().decode()))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().exa_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def darr(vals):
+    return (C.c_double * len(vals))(*[float(v) for v in vals])
+
+
+def larr(vals):
+    return (C.c_long * len(vals))(*[int(v) for v in vals])

@@ -1,0 +1,85 @@
+"""Build libexahype_hip.so (gfx950) in-tree with hipcc.
+
+    python -m exahype_amd.build [--force] [--jobs N]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so travels to the
+GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "lib", "libexahype_hip.so")
+ARCH = "gfx950"
+
+COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Wno-pass-failed", "-I", CSRC]
+
+# (source, object stem, extra flags)
+UNITS = [
+    ("capi.cpp", "capi", ["-x", "hip"]),
+    ("dg_operators_host.cpp", "dg_operators_host", ["-x", "hip"]),
+    # bit-exact with the g++ build of the reference: no FMA contraction in the FV unit
+    ("fv_rusanov.hip", "fv_rusanov", ["-ffp-contract=off"]),
+] + [
+    ("dg_inst.hip", f"dg_{dim}_{pde}", [f"-DEXA_DIM={dim}", f"-DEXA_PDE_ID={pde}"])
+    for dim, pde in ((3, 1), (2, 1), (2, 0), (3, 2), (2, 2))
+]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libexahype_hip.so cannot be built")
+    return exe
+
+
+def _sources_mtime():
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return max(m, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def _compile(unit, verbose):
+    src, stem, extra = unit
+    obj = os.path.join(OBJ, stem + ".o")
+    cmd = [_hipcc()] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (stem, " ".join(cmd), r.stderr[-4000:]))
+    if verbose and r.stderr.strip():
+        print(r.stderr[-2000:], file=sys.stderr)
+    return obj
+
+
+def build(force=False, jobs=None, verbose=False):
+    """Compile every unit (in parallel) and link the shared library; returns its path."""
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _sources_mtime():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda u: _compile(u, verbose), UNITS))
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("-v", "--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.jobs, a.verbose))

@@ -1,0 +1,346 @@
+// C-ABI of libexahype_hip.so (include/exahype_hip.h).  Host-side only: argument
+// checking, plan bookkeeping, staging for the *_host convenience calls, and
+// dispatch into the kernel units.  Never throws; every failure sets the
+// thread-local message behind exa_last_error().
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include "../../include/exahype_hip.h"
+#include "exa_launch.hpp"
+
+namespace exa {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define EXA_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return EXA_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+const DgLaunchTable *dg_table_2_0(), *dg_table_2_1(), *dg_table_2_2(), *dg_table_3_1(), *dg_table_3_2();
+
+const DgLaunchTable* dg_launch_table(int dim, int pde) {
+    if (dim == 2 && pde == 0) return dg_table_2_0();
+    if (dim == 2 && pde == 1) return dg_table_2_1();
+    if (dim == 2 && pde == 2) return dg_table_2_2();
+    if (dim == 3 && pde == 1) return dg_table_3_1();
+    if (dim == 3 && pde == 2) return dg_table_3_2();
+    return nullptr;
+}
+
+static long lpow(long b, int e) { long r = 1; while (e-- > 0) r *= b; return r; }
+
+}  // namespace exa
+
+using namespace exa;
+
+struct exa_fv_plan {
+    int device, mode, dim, P, H, n_real, n_aux, pde;
+    long n_patches, count;
+};
+
+struct exa_dg_plan {
+    int device, dim, N, nv, pde, n_it;
+    long nc[3], ncells;
+    const DgLaunchTable* tab;
+    DgOpsHost ops;
+};
+
+extern "C" {
+
+int exa_version(void) { return 100; }
+
+const char* exa_last_error(void) { return g_err; }
+
+int exa_device_count(int* count) {
+    if (!count) { set_error("exa_device_count: NULL argument"); return EXA_ERR_INVALID; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return EXA_ERR_NO_DEVICE; }
+    *count = n;
+    return EXA_OK;
+}
+
+static int use_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libexahype_hip has no CPU fallback", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return EXA_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return EXA_ERR_INVALID; }
+    EXA_HIP(hipSetDevice(device));
+    return EXA_OK;
+}
+
+int exa_pde_eval_device(int pde, int normal, long n, int stride, const double* Q_dev, double* F_dev, double* lambda_dev,
+                        void* stream) {
+    if (pde < 0 || pde > 2 || normal < 0 || normal > 2 || n < 0 || stride < 1 || !Q_dev) {
+        set_error("exa_pde_eval_device: bad argument");
+        return EXA_ERR_INVALID;
+    }
+    if (pde == EXA_PDE_EULER_REF2D && (normal > 1 || stride < 4)) { set_error("EULER_REF2D needs normal < 2 and stride >= 4"); return EXA_ERR_INVALID; }
+    if (pde == EXA_PDE_EULER && stride < 5) { set_error("EULER needs stride >= 5"); return EXA_ERR_INVALID; }
+    return pde_eval_launch(pde, normal, n, stride, Q_dev, F_dev, lambda_dev, (hipStream_t)stream);
+}
+
+/* ---- FV ---------------------------------------------------------------------- */
+
+int exa_fv_plan_create(int device, int mode, int dim, int patch_size, int halo_size, int n_real, int n_aux,
+                       long n_patches, int pde, exa_fv_plan** plan) {
+    if (!plan) { set_error("exa_fv_plan_create: NULL plan"); return EXA_ERR_INVALID; }
+    *plan = nullptr;
+    // same viability rule as the reference's KernelBuilder (exahype/KernelBuilder.py:41-48) ...
+    if ((dim != 2 && dim != 3) || patch_size < 1 || halo_size < 0) { set_error("check viability of inputs"); return EXA_ERR_INVALID; }
+    // ... plus what the 3-point stencil itself needs
+    if (halo_size < 1) { set_error("the Rusanov stencil reads one halo layer: halo_size must be >= 1"); return EXA_ERR_INVALID; }
+    if (mode != EXA_FV_FAITHFUL && mode != EXA_FV_RUSANOV) { set_error("unknown FV mode %d", mode); return EXA_ERR_INVALID; }
+    if (n_real < 1 || n_real > 8 || n_aux < 0 || n_patches < 0) { set_error("n_real must be 1..8, n_aux >= 0, n_patches >= 0"); return EXA_ERR_INVALID; }
+    if (pde == EXA_PDE_EULER_REF2D && (dim != 2 || n_real < 4)) { set_error("EULER_REF2D is the reference's 2-D term set (n_real >= 4)"); return EXA_ERR_INVALID; }
+    if (pde == EXA_PDE_EULER && n_real < 5) { set_error("EULER needs n_real >= 5"); return EXA_ERR_INVALID; }
+    if (pde < 0 || pde > 2) { set_error("unknown pde %d", pde); return EXA_ERR_INVALID; }
+    const long ncell = lpow(patch_size, dim);
+    if (ncell > 4096) { set_error("FV patch with %ld volumes exceeds the 4096 a workgroup keeps in registers", ncell); return EXA_ERR_INVALID; }
+    int rc = use_device(device);
+    if (rc) return rc;
+    exa_fv_plan* p = new (std::nothrow) exa_fv_plan;
+    if (!p) { set_error("out of host memory"); return EXA_ERR_ALLOC; }
+    p->device = device; p->mode = mode; p->dim = dim; p->P = patch_size; p->H = halo_size;
+    p->n_real = n_real; p->n_aux = n_aux; p->pde = pde; p->n_patches = n_patches;
+    p->count = n_patches * lpow(patch_size + 2 * halo_size, dim) * (n_real + n_aux);
+    *plan = p;
+    return EXA_OK;
+}
+
+int exa_fv_plan_destroy(exa_fv_plan* plan) { delete plan; return EXA_OK; }
+
+long exa_fv_q_count(const exa_fv_plan* plan) { return plan ? plan->count : 0; }
+
+int exa_fv_time_step_device(exa_fv_plan* p, double* Q_dev, double dt, double h, void* stream) {
+    if (!p || !Q_dev) { set_error("exa_fv_time_step_device: NULL argument"); return EXA_ERR_INVALID; }
+    if (p->mode == EXA_FV_RUSANOV && !(h > 0.0)) { set_error("EXA_FV_RUSANOV needs the volume size h > 0"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, dt, h, (hipStream_t)stream);
+}
+
+int exa_fv_time_step_host(exa_fv_plan* p, double* Q_host, double dt, double h) {
+    if (!p || !Q_host) { set_error("exa_fv_time_step_host: NULL argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    if (p->count == 0) return EXA_OK;
+    double* d = nullptr;
+    const size_t bytes = (size_t)p->count * sizeof(double);
+    EXA_HIP(hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpy(d, Q_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = exa_fv_time_step_device(p, d, dt, h, nullptr);
+        if (rc == EXA_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(Q_host, d, bytes, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("exa_fv_time_step_host: %s", hipGetErrorString(e)); return EXA_ERR_HIP; }
+    return EXA_OK;
+}
+
+/* ---- DG ---------------------------------------------------------------------- */
+
+int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_picard, const long* ncells,
+                       exa_dg_plan** plan) {
+    if (!plan || !ncells) { set_error("exa_dg_plan_create: NULL argument"); return EXA_ERR_INVALID; }
+    *plan = nullptr;
+    if (dim != 2 && dim != 3) { set_error("check viability of inputs"); return EXA_ERR_INVALID; }
+    const DgLaunchTable* tab = dg_launch_table(dim, pde);
+    if (!tab) { set_error("ADER-DG: no kernels for dim %d, pde %d", dim, pde); return EXA_ERR_INVALID; }
+    if (N < 2 || N > tab->max_n) {
+        set_error("ADER-DG: N = %d unsupported for dim %d (2..%d; larger cells exceed the 160 KiB LDS image)", N, dim, tab->max_n);
+        return EXA_ERR_INVALID;
+    }
+    if (n_vars != tab->nv) { set_error("ADER-DG: pde %d evolves %d variables, got n_vars = %d", pde, tab->nv, n_vars); return EXA_ERR_INVALID; }
+    long nc = 1;
+    for (int d = 0; d < dim; d++) {
+        if (ncells[d] < 1) { set_error("ncells[%d] = %ld", d, ncells[d]); return EXA_ERR_INVALID; }
+        nc *= ncells[d];
+    }
+    int rc = use_device(device);
+    if (rc) return rc;
+    exa_dg_plan* p = new (std::nothrow) exa_dg_plan;
+    if (!p) { set_error("out of host memory"); return EXA_ERR_ALLOC; }
+    p->device = device; p->dim = dim; p->N = N; p->nv = n_vars; p->pde = pde;
+    p->n_it = n_picard < 0 ? N : n_picard;
+    p->nc[0] = ncells[0]; p->nc[1] = ncells[1]; p->nc[2] = dim == 3 ? ncells[2] : 1;
+    p->ncells = nc;
+    p->tab = tab;
+    if (build_dg_operators(N, &p->ops) != 0) { delete p; set_error("operator construction failed for N = %d", N); return EXA_ERR_INVALID; }
+    *plan = p;
+    return EXA_OK;
+}
+
+int exa_dg_plan_destroy(exa_dg_plan* plan) { delete plan; return EXA_OK; }
+
+long exa_dg_dof_count(const exa_dg_plan* p) { return p ? p->ncells * lpow(p->N, p->dim) * p->nv : 0; }
+long exa_dg_trace_count(const exa_dg_plan* p) { return p ? (long)p->dim * 2 * p->ncells * 2 * p->nv * lpow(p->N, p->dim - 1) : 0; }
+long exa_dg_face_count(const exa_dg_plan* p, int d) {
+    if (!p || d < 0 || d >= p->dim) return 0;
+    return (p->ncells / p->nc[d]) * 2 * p->nv * lpow(p->N, p->dim - 1);
+}
+
+int exa_dg_operators(const exa_dg_plan* p, double* xi, double* w, double* D, double* Kxi, double* phiL, double* phiR,
+                     double* iK1) {
+    if (!p) { set_error("exa_dg_operators: NULL plan"); return EXA_ERR_INVALID; }
+    const int N = p->N;
+    if (xi) memcpy(xi, p->ops.xi, N * sizeof(double));
+    if (w) memcpy(w, p->ops.w, N * sizeof(double));
+    if (D) memcpy(D, p->ops.D, N * N * sizeof(double));
+    if (Kxi) memcpy(Kxi, p->ops.Kxi, N * N * sizeof(double));
+    if (phiL) memcpy(phiL, p->ops.phiL, N * sizeof(double));
+    if (phiR) memcpy(phiR, p->ops.phiR, N * sizeof(double));
+    if (iK1) memcpy(iK1, p->ops.iK1, N * N * sizeof(double));
+    return EXA_OK;
+}
+
+int exa_dg_work(const exa_dg_plan* p, double* fa, double* fb, double* ba, double* bb) {
+    if (!p) { set_error("exa_dg_work: NULL plan"); return EXA_ERR_INVALID; }
+    // c_F = c_lambda = 20 flop
+    const double d = p->dim, m = p->nv, N = p->N, cF = 20, cL = 20;
+    const double Nd = (double)lpow(p->N, p->dim), Nd1 = Nd * N, Nd2 = Nd1 * N, Nf = Nd / N;
+    double a;
+    if (p->n_it > 0) a = p->n_it * (2 * (d + 1) * m * Nd2 + d * cF * Nd1) + 2 * (d + 1) * m * Nd1 + 2 * d * m * Nd1 + 8 * d * m * Nd;
+    else a = d * cF * Nd + 2 * d * m * Nd1 + 8 * d * m * Nd;
+    const double b = d * Nf * (2 * cL + 6 * m) + 4 * d * m * Nd;
+    if (fa) *fa = a * p->ncells;
+    if (fb) *fb = b * p->ncells;
+    if (ba) *ba = (16 * m * Nd + 32 * d * m * Nf) * p->ncells;   // u read + u* written + traces written
+    if (bb) *bb = (16 * m * Nd + 64 * d * m * Nf) * p->ncells;   // u* read + u written + own and neighbour traces read
+    return EXA_OK;
+}
+
+static void inv_dx(const exa_dg_plan* p, const double* dx, double* idx) {
+    for (int d = 0; d < 3; d++) idx[d] = d < p->dim ? 1.0 / dx[d] : 0.0;
+}
+
+static int make_box(const exa_dg_plan* p, const long* lo, const long* hi, CellBox* box) {
+    box->nbox = 1;
+    for (int d = 0; d < 3; d++) {
+        box->nc[d] = p->nc[d];
+        box->lo[d] = (lo && d < p->dim) ? lo[d] : 0;
+        const long h = (hi && d < p->dim) ? hi[d] : p->nc[d];
+        if (box->lo[d] < 0 || h > p->nc[d] || h < box->lo[d]) {
+            set_error("cell box [%ld,%ld) outside the block in direction %d", box->lo[d], h, d);
+            return EXA_ERR_INVALID;
+        }
+        box->nb[d] = h - box->lo[d];
+        box->nbox *= box->nb[d];
+    }
+    return EXA_OK;
+}
+
+int exa_dg_predictor_volume_box(exa_dg_plan* p, double* u_dev, double* trace_dev, const long* lo, const long* hi, double dt,
+                                const double* dx, void* stream) {
+    if (!p || !u_dev || !trace_dev || !dx) { set_error("exa_dg_predictor_volume: NULL argument"); return EXA_ERR_INVALID; }
+    for (int d = 0; d < p->dim; d++)
+        if (!(dx[d] > 0.0)) { set_error("dx[%d] must be > 0", d); return EXA_ERR_INVALID; }
+    CellBox box;
+    int rc = make_box(p, lo, hi, &box);
+    if (rc) return rc;
+    rc = use_device(p->device);
+    if (rc) return rc;
+    double idx[3];
+    inv_dx(p, dx, idx);
+    return p->tab->stage_a(p->N, u_dev, u_dev, trace_dev, p->ncells, &box, dt, idx, p->n_it, &p->ops, (hipStream_t)stream);
+}
+
+int exa_dg_predictor_volume(exa_dg_plan* p, double* u_dev, double* trace_dev, double dt, const double* dx, void* stream) {
+    return exa_dg_predictor_volume_box(p, u_dev, trace_dev, nullptr, nullptr, dt, dx, stream);
+}
+
+int exa_dg_riemann_corrector(exa_dg_plan* p, double* u_dev, const double* trace_dev, const double* const* ghost_dev,
+                             const long* lo, const long* hi, double dt, const double* dx, void* stream) {
+    if (!p || !u_dev || !trace_dev || !dx) { set_error("exa_dg_riemann_corrector: NULL argument"); return EXA_ERR_INVALID; }
+    StageBBox box;
+    CellBox cb;
+    int rcb = make_box(p, lo, hi, &cb);
+    if (rcb) return rcb;
+    for (int d = 0; d < 3; d++) { box.nc[d] = cb.nc[d]; box.lo[d] = cb.lo[d]; box.nb[d] = cb.nb[d]; }
+    for (int f = 0; f < 6; f++) box.ghost[f] = (ghost_dev && f < 2 * p->dim) ? ghost_dev[f] : nullptr;
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    double idx[3];
+    inv_dx(p, dx, idx);
+    return p->tab->stage_b(p->N, u_dev, trace_dev, &box, p->ncells, dt, idx, &p->ops, (hipStream_t)stream);
+}
+
+int exa_dg_pack_face(exa_dg_plan* p, const double* trace_dev, int d, int side, double* buf_dev, void* stream) {
+    if (!p || !trace_dev || !buf_dev || d < 0 || d >= p->dim || side < 0 || side > 1) { set_error("exa_dg_pack_face: bad argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    // trace[(d*2+side)][cx][cy][cz][TS] -> the layer c_d = 0 (side 0) or nc_d-1 (side 1) as a strided 2-D copy
+    const long TS = 2L * p->nv * lpow(p->N, p->dim - 1);
+    long outer = 1, inner = 1;
+    for (int a = 0; a < d; a++) outer *= p->nc[a];
+    for (int a = d + 1; a < 3; a++) inner *= p->nc[a];
+    const long layer = side ? p->nc[d] - 1 : 0;
+    const double* src = trace_dev + ((long)(d * 2 + side) * p->ncells + layer * inner) * TS;
+    EXA_HIP(hipMemcpy2DAsync(buf_dev, (size_t)inner * TS * sizeof(double), src, (size_t)p->nc[d] * inner * TS * sizeof(double),
+                             (size_t)inner * TS * sizeof(double), (size_t)outer, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EXA_OK;
+}
+
+int exa_dg_max_eigenvalue(exa_dg_plan* p, const double* u_dev, double* lambda_dev, void* stream) {
+    if (!p || !u_dev || !lambda_dev) { set_error("exa_dg_max_eigenvalue: NULL argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    return p->tab->maxeig(u_dev, p->ncells * lpow(p->N, p->dim), lambda_dev, (hipStream_t)stream);
+}
+
+int exa_dg_step_periodic(exa_dg_plan* p, double* u_dev, double* trace_dev, double dt, const double* dx, int n_steps,
+                         void* stream) {
+    for (int s = 0; s < n_steps; s++) {
+        int rc = exa_dg_predictor_volume(p, u_dev, trace_dev, dt, dx, stream);
+        if (rc) return rc;
+        rc = exa_dg_riemann_corrector(p, u_dev, trace_dev, nullptr, nullptr, nullptr, dt, dx, stream);
+        if (rc) return rc;
+    }
+    return EXA_OK;
+}
+
+int exa_dg_step_host(exa_dg_plan* p, double* u_host, double dt, const double* dx, int n_steps) {
+    if (!p || !u_host || !dx) { set_error("exa_dg_step_host: NULL argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    double *u = nullptr, *tr = nullptr;
+    const size_t ub = (size_t)exa_dg_dof_count(p) * sizeof(double), tb = (size_t)exa_dg_trace_count(p) * sizeof(double);
+    EXA_HIP(hipMalloc(&u, ub));
+    hipError_t e = hipMalloc(&tr, tb);
+    if (e == hipSuccess) e = hipMemcpy(u, u_host, ub, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = exa_dg_step_periodic(p, u, tr, dt, dx, n_steps, nullptr);
+        if (rc == EXA_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(u_host, u, ub, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(u);
+    (void)hipFree(tr);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("exa_dg_step_host: %s", hipGetErrorString(e)); return EXA_ERR_HIP; }
+    return EXA_OK;
+}
+
+}  // extern "C"

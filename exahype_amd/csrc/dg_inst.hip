@@ -1,0 +1,160 @@
+// One instantiation unit of the ADER-DG kernels, compiled once per
+// (EXA_DIM, EXA_PDE_ID) pair (see exahype_amd/build.py) so the heavy fully
+// unrolled kernels build in parallel.
+#include <cstdio>
+#include "exa_dg_kernels.hpp"
+#include "exa_launch.hpp"
+
+#ifndef EXA_DIM
+#error "compile with -DEXA_DIM=2|3 -DEXA_PDE_ID=0|1|2"
+#endif
+
+namespace exa {
+
+#if EXA_PDE_ID == 0
+using PDE = EulerRef2D;
+#elif EXA_PDE_ID == 1
+using PDE = Euler;
+#elif EXA_PDE_ID == 2
+using PDE = Advection<1>;
+#endif
+
+constexpr int DIM = EXA_DIM;
+#if EXA_DIM == 3
+constexpr int MAX_N = 6;                       // N = 7, 8 need > 160 KiB of LDS per cell
+constexpr int NT_A = 256;
+__host__ __device__ constexpr int cpb_of(int N) { return N == 2 ? 16 : N == 3 ? 8 : N == 4 ? 4 : N == 5 ? 2 : 1; }
+#else
+constexpr int MAX_N = 8;
+constexpr int NT_A = 128;
+__host__ __device__ constexpr int cpb_of(int N) { return (128 / (N * N)) > 0 ? 128 / (N * N) : 1; }
+#endif
+
+template <int N> static DgOps<N> pack_ops(const DgOpsHost* h) {
+    DgOps<N> o;
+    for (int i = 0; i < N; i++) {
+        o.w[i] = h->w[i];
+        o.iw[i] = 1.0 / h->w[i];
+        o.phiL[i] = h->phiL[i];
+        o.phiR[i] = h->phiR[i];
+        for (int j = 0; j < N; j++) {
+            o.D[i * N + j] = h->D[i * N + j];
+            o.Kxi[i * N + j] = h->Kxi[i * N + j];
+            o.T[i * N + j] = h->iK1[i * N + j] * h->w[j];
+        }
+    }
+    return o;
+}
+
+template <int N>
+static int launch_a(const double* u_in, double* u_out, double* trace, long ncells, const CellBox* box, double dt,
+                    const double* idx, int n_it, const DgOpsHost* ops, hipStream_t s) {
+    constexpr int CPB = cpb_of(N);
+    using SA = StageA<DIM, N, PDE, CPB>;
+    static_assert(SA::LDS_BYTES <= 160 * 1024, "cell image exceeds the 160 KiB LDS of a gfx950 CU");
+    auto kern = dg_stage_a_kernel<DIM, N, PDE, CPB, NT_A>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)SA::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(stage_a, %zu B LDS): %s", SA::LDS_BYTES, hipGetErrorString(e));
+            return -2;
+        }
+        attr_set = true;
+    }
+    if (box->nbox <= 0) return 0;
+    const long nblocks = (box->nbox + CPB - 1) / CPB;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT_A), SA::LDS_BYTES, s, u_in, u_out, trace, ncells, *box, dt,
+                       idx[0], idx[1], idx[2], n_it, pack_ops<N>(ops));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("stage_a launch (dim %d, N %d): %s", DIM, N, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+template <int N>
+static int launch_b(double* u, const double* trace, const StageBBox* box, long ncells, double dt, const double* idx,
+                    const DgOpsHost* ops, hipStream_t s) {
+    constexpr int NT_B = 256;
+    constexpr int NFN = 2 * DIM * ipow(N, DIM - 1);
+    constexpr int CPB = (NT_B / NFN) > 0 ? NT_B / NFN : 1;
+    StageBArgs A;
+    long nbox = 1;
+    for (int d = 0; d < 3; d++) {
+        A.nc[d] = box->nc[d];
+        A.lo[d] = box->lo[d];
+        A.nb[d] = box->nb[d];
+        nbox *= box->nb[d];
+    }
+    for (int f = 0; f < 6; f++) A.ghost[f] = box->ghost[f];
+    if (nbox <= 0) return 0;
+    const long nblocks = (nbox + CPB - 1) / CPB;
+    hipLaunchKernelGGL((dg_stage_b_kernel<DIM, N, PDE, CPB, NT_B>), dim3((unsigned)nblocks), dim3(NT_B), 0, s, u, trace, A,
+                       ncells, nbox, dt, idx[0], idx[1], idx[2], pack_ops<N>(ops));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("stage_b launch (dim %d, N %d): %s", DIM, N, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+#define EXA_N_CASES(X) X(2) X(3) X(4) X(5) X(6)
+#if EXA_DIM == 2
+#define EXA_N_CASES_HI(X) X(7) X(8)
+#else
+#define EXA_N_CASES_HI(X)
+#endif
+
+static int stage_a(int N, const double* u_in, double* u_out, double* trace, long ncells, const CellBox* box, double dt,
+                   const double* idx, int n_it, const DgOpsHost* ops, hipStream_t s) {
+    switch (N) {
+#define X(n) case n: return launch_a<n>(u_in, u_out, trace, ncells, box, dt, idx, n_it, ops, s);
+        EXA_N_CASES(X)
+        EXA_N_CASES_HI(X)
+#undef X
+    }
+    set_error("ADER-DG stage A: N = %d is not built for dim %d (supported 2..%d)", N, DIM, MAX_N);
+    return -1;
+}
+
+static int stage_b(int N, double* u, const double* trace, const StageBBox* box, long ncells, double dt,
+                   const double* idx, const DgOpsHost* ops, hipStream_t s) {
+    switch (N) {
+#define X(n) case n: return launch_b<n>(u, trace, box, ncells, dt, idx, ops, s);
+        EXA_N_CASES(X)
+        EXA_N_CASES_HI(X)
+#undef X
+    }
+    set_error("ADER-DG stage B: N = %d is not built for dim %d (supported 2..%d)", N, DIM, MAX_N);
+    return -1;
+}
+
+static int maxeig(const double* u, long nnodes, double* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), s);
+    if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return -2; }
+    long nb = (nnodes + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL((dg_maxeig_kernel<DIM, PDE>), dim3((unsigned)nb), dim3(256), 0, s, u, nnodes, out);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error("maxeig launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+#define EXA_CAT_(a, b, c) a##b##_##c
+#define EXA_CAT(a, b, c) EXA_CAT_(a, b, c)
+// (a function, not a const global: a const global with a constant initialiser is also emitted for the device)
+const DgLaunchTable* EXA_CAT(dg_table_, EXA_DIM, EXA_PDE_ID)() {
+    static DgLaunchTable t;
+    t.nv = PDE::NV;
+    t.max_n = MAX_N;
+    t.stage_a = stage_a;
+    t.stage_b = stage_b;
+    t.maxeig = maxeig;
+    return &t;
+}
+
+}  // namespace exa

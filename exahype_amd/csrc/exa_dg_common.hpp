@@ -1,0 +1,87 @@
+// Shared compile-time geometry and the reference-element operator block for the
+// ADER-DG kernels (no counterpart in the reference).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace exa {
+
+constexpr int MAXN = 8;
+
+__host__ __device__ constexpr int ipow(int b, int e) { return e <= 0 ? 1 : b * ipow(b, e - 1); }
+
+// 1-D operators, passed BY VALUE as a kernel argument: the kernarg segment is
+// read with scalar loads, so every matrix entry becomes an SGPR operand of
+// v_fma_f64 and costs no VGPR / LDS traffic.
+template <int N> struct DgOps {
+    double w[N];        // Gauss-Legendre weights on [0,1]
+    double iw[N];       // 1 / w
+    double D[N * N];    // D[i][j]   = phi_j'(xi_i)
+    double Kxi[N * N];  // Kxi[i][j] = w_j D[j][i]
+    double T[N * N];    // T[l'][l]  = iK1[l'][l] * w_l   (time update; uses iK1*F0 = 1)
+    double phiL[N];
+    double phiR[N];
+};
+
+// LDS image of one cell: SoA [var][time slab][padded node].  The node index is
+// lexicographic (i slowest) with the i-stride padded so that pencils along any
+// axis hit distinct banks for the 32-lane ds_read_b64 groups
+// (MI355X_MICROARCH.md, LDS table: bank = (addr/4) mod 64 for b64).
+template <int DIM, int N> struct Geo {
+    static constexpr int NN = ipow(N, DIM);       // nodes per cell
+    static constexpr int NF = ipow(N, DIM - 1);   // nodes per face
+    static constexpr int PAD = (DIM == 3) ? 2 : 1;
+    static constexpr int SI = ((DIM == 3) ? N * N : N) + PAD;  // stride of axis 0
+    static constexpr int SL = N * SI;                           // one (var, slab) image
+    static constexpr int NTS = (N > DIM + 1) ? N : DIM + 1;     // slabs per variable
+
+    // padded offset of lexicographic node n
+    __device__ static inline int node_off(int n) {
+        if constexpr (DIM == 3) return (n / (N * N)) * SI + (n % (N * N));
+        else return (n / N) * SI + (n % N);
+    }
+    // axis-0 coordinate etc. of node n
+    __device__ static inline int coord(int n, int d) {
+        if constexpr (DIM == 3) return d == 0 ? n / (N * N) : (d == 1 ? (n / N) % N : n % N);
+        else return d == 0 ? n / N : n % N;
+    }
+    // stride between consecutive nodes of a pencil along axis d
+    __device__ static constexpr int pstride(int d) {
+        if constexpr (DIM == 3) return d == 0 ? SI : (d == 1 ? N : 1);
+        else return d == 0 ? SI : 1;
+    }
+    // padded offset of the first node of pencil t (t = lexicographic index of the
+    // remaining axes == the face-node index y of the traces)
+    __device__ static inline int pbase(int d, int t) {
+        if constexpr (DIM == 3) {
+            if (d == 0) return t;                          // (j,k)
+            if (d == 1) return (t / N) * SI + (t % N);     // (i,k)
+            return (t / N) * SI + (t % N) * N;             // (i,j)
+        } else {
+            return d == 0 ? t : t * SI;
+        }
+    }
+    // face-node index y (for direction d) of lexicographic node n
+    __device__ static inline int face_index(int n, int d) {
+        if constexpr (DIM == 3) {
+            const int i = n / (N * N), j = (n / N) % N, k = n % N;
+            return d == 0 ? j * N + k : (d == 1 ? i * N + k : i * N + j);
+        } else {
+            return d == 0 ? n % N : n / N;
+        }
+    }
+};
+
+// A box [lo, lo+nb) of cells inside the local block nc[3] (nc[2] = nb[2] = 1 in 2-D);
+// box slots are enumerated lexicographically, last axis fastest.
+struct CellBox {
+    long nc[3], lo[3], nb[3], nbox;
+    __host__ __device__ inline long cell(long b) const {
+        if (b >= nbox) return -1;
+        const long cz = b % nb[2];
+        b /= nb[2];
+        const long cy = b % nb[1], cx = b / nb[1];
+        return ((lo[0] + cx) * nc[1] + lo[1] + cy) * nc[2] + lo[2] + cz;
+    }
+};
+
+}  // namespace exa

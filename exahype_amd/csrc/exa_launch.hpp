@@ -1,0 +1,43 @@
+// Host-side glue between the C-ABI (capi.cpp) and the per-(dim, pde) kernel
+// instantiation units (dg_inst.hip, fv_rusanov.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "exa_dg_common.hpp"
+
+namespace exa {
+
+// reference-element tables for any N <= MAXN (host copy held by the plan)
+struct DgOpsHost {
+    int N;
+    double xi[MAXN], w[MAXN], D[MAXN * MAXN], Kxi[MAXN * MAXN], phiL[MAXN], phiR[MAXN], iK1[MAXN * MAXN],
+        K1[MAXN * MAXN];
+};
+// dg_operators_host.cpp: Gauss-Legendre nodes by Newton, barycentric derivative
+// matrix, K1 inverse by Gauss-Jordan, all in long double.
+int build_dg_operators(int N, DgOpsHost* out);
+
+struct StageBBox {
+    long nc[3], lo[3], nb[3];
+    const double* ghost[6];
+};
+
+struct DgLaunchTable {
+    int nv;        // variables the PDE evolves
+    int max_n;     // largest N instantiated
+    int (*stage_a)(int N, const double* u_in, double* u_out, double* trace, long ncells, const CellBox* box, double dt,
+                   const double* idx, int n_it, const DgOpsHost* ops, hipStream_t s);
+    int (*stage_b)(int N, double* u, const double* trace, const StageBBox* box, long ncells, double dt,
+                   const double* idx, const DgOpsHost* ops, hipStream_t s);
+    int (*maxeig)(const double* u, long nnodes, double* out, hipStream_t s);
+};
+// returns nullptr when (dim, pde) is not built
+const DgLaunchTable* dg_launch_table(int dim, int pde);
+
+// fv_rusanov.hip
+int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
+              double h, hipStream_t s);
+int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
+
+void set_error(const char* fmt, ...);
+
+}  // namespace exa

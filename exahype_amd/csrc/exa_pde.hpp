@@ -1,0 +1,128 @@
+// Device twins of the reference's user PDE terms (`Unit test/Functions.cpp:9-66`).
+//
+// The reference resolves `Flux` / `maxEigenvalue` / `max` at link time to host
+// C++ (`Unit test/Functions.h:2-4`); a HIP kernel cannot call those, so the
+// kernels are templated on one of these structs instead.
+//
+// Interface every PDE struct provides:
+//   NV        variables the scheme evolves (n_real)
+//   NFLUX     leading entries of F that flux() writes (rest are left alone)
+//   NAUX      per-node cached scalars shared by the flux in every direction
+//   aux(q, a)                  a[NAUX] from q[NV]   (Euler: 1/rho and p)
+//   flux<d>(q, a, F)           F[NV] for normal d using the cached scalars
+//   flux_rt(q, d, F)           same, run-time normal, no cache (FV path, traces)
+//   maxeig(q, d)               largest absolute eigenvalue along d
+//
+// Arithmetic order follows Functions.cpp exactly (irho first, p from irho, coeff =
+// irho*Q[normal+1], F[normal+1] += p), so results agree with the CPU path to
+// rounding; the FV faithful kernel compiles these with FP contraction off and is
+// bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace exa {
+
+constexpr double GAMMA = 1.4;
+
+// Functions.cpp:9-62 as the reference compiles it (`Dimensions` undefined -> 2-D
+// branch): state (rho, rho u, rho v, E) in Q[0..3]; F[0..3] written.
+struct EulerRef2D {
+    static constexpr int NV = 5;      // the reference runs it with n_real = 5 (F[4] never written)
+    static constexpr int NFLUX = 4;
+    static constexpr int NAUX = 2;
+    static constexpr int MAXDIM = 2;
+    __device__ static inline void aux(const double* q, double* a) {
+        const double irho = 1.0 / q[0];
+        a[0] = irho;
+        a[1] = (GAMMA - 1) * (q[3] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2]));
+    }
+    template <int D> __device__ static inline void flux(const double* q, const double* a, double* F) {
+        const double coeff = a[0] * q[D + 1];
+        F[0] = coeff * q[0];
+        F[1] = coeff * q[1];
+        F[2] = coeff * q[2];
+        F[3] = coeff * q[3] + coeff * a[1];
+        F[D + 1] += a[1];
+        F[4] = 0.0;
+    }
+    __device__ static inline void flux_rt(const double* q, int d, double* F) {
+        const double irho = 1.0 / q[0];
+        const double p = (GAMMA - 1) * (q[3] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2]));
+        const double coeff = irho * q[d + 1];
+        F[0] = coeff * q[0];
+        F[1] = coeff * q[1];
+        F[2] = coeff * q[2];
+        F[3] = coeff * q[3] + coeff * p;
+        F[d + 1] += p;
+    }
+    __device__ static inline double maxeig(const double* q, int d) {
+        const double irho = 1.0 / fabs(q[0]);
+        const double p = (GAMMA - 1) * (q[3] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2]));
+        const double c = sqrt(GAMMA * fabs(p) * irho);
+        const double un = q[d + 1] * irho;
+        return fmax(fabs(un - c), fabs(un + c));
+    }
+};
+
+// Same arithmetic with a 3-component momentum: (rho, m0, m1, m2, E).  This is the
+// 3-D branch of Functions.cpp without its stray `F[3] = ...` overwrite
+// (SURVEY.md Appendix B-4).
+struct Euler {
+    static constexpr int NV = 5;
+    static constexpr int NFLUX = 5;
+    static constexpr int NAUX = 2;
+    static constexpr int MAXDIM = 3;
+    __device__ static inline void aux(const double* q, double* a) {
+        const double irho = 1.0 / q[0];
+        a[0] = irho;
+        a[1] = (GAMMA - 1) * (q[4] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+    }
+    template <int D> __device__ static inline void flux(const double* q, const double* a, double* F) {
+        const double coeff = a[0] * q[D + 1];
+        F[0] = coeff * q[0];
+        F[1] = coeff * q[1];
+        F[2] = coeff * q[2];
+        F[3] = coeff * q[3];
+        F[4] = coeff * q[4] + coeff * a[1];
+        F[D + 1] += a[1];
+    }
+    __device__ static inline void flux_rt(const double* q, int d, double* F) {
+        double a[2];
+        aux(q, a);
+        const double coeff = a[0] * q[d + 1];
+        F[0] = coeff * q[0];
+        F[1] = coeff * q[1];
+        F[2] = coeff * q[2];
+        F[3] = coeff * q[3];
+        F[4] = coeff * q[4] + coeff * a[1];
+        F[d + 1] += a[1];
+    }
+    __device__ static inline double maxeig(const double* q, int d) {
+        const double irho = 1.0 / fabs(q[0]);
+        const double p = (GAMMA - 1) * (q[4] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+        const double c = sqrt(GAMMA * fabs(p) * irho);
+        const double un = q[d + 1] * irho;
+        return fmax(fabs(un - c), fabs(un + c));
+    }
+};
+
+// Linear advection of NVARS variables with a fixed velocity (known-answer tests).
+template <int NVARS> struct Advection {
+    static constexpr int NV = NVARS;
+    static constexpr int NFLUX = NVARS;
+    static constexpr int NAUX = 1;     // unused slot (keeps array sizes non-zero)
+    static constexpr int MAXDIM = 3;
+    __device__ static inline double vel(int d) { return d == 0 ? 1.0 : (d == 1 ? 0.5 : -0.75); }
+    __device__ static inline void aux(const double*, double* a) { a[0] = 0.0; }
+    template <int D> __device__ static inline void flux(const double* q, const double*, double* F) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) F[v] = vel(D) * q[v];
+    }
+    __device__ static inline void flux_rt(const double* q, int d, double* F) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) F[v] = vel(d) * q[v];
+    }
+    __device__ static inline double maxeig(const double*, int d) { return fabs(vel(d)); }
+};
+
+}  // namespace exa

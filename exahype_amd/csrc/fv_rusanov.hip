@@ -1,0 +1,208 @@
+// Fused Finite-Volume Rusanov patch update for gfx950 -- the device form of the
+// reference's generated kernel `time_step` (`Unit test/test.cpp:3-111`, what
+// `exahype/printers/CPPPrinter.py:84-90` emits for the statement list of
+// `examples/Batched_stateless.py:25-35`).
+//
+// The reference runs ten separate sweeps over heap temporaries (Q_copy,
+// tmp_flux_{x,y}, tmp_eigen_{x,y}); here one workgroup owns one patch, every
+// thread evaluates the whole stencil of its volumes in registers (flux and
+// eigenvalue of the 2*dim neighbours are recomputed instead of staged), a
+// workgroup barrier separates the last read of the patch from the first write,
+// and the result goes back in place -- Q is read once and written once.
+//
+// MODE 0 (faithful): exactly the arithmetic and evaluation order of
+//   test.cpp:60-95 (no dt/h, dissipation on variable 0 only, reference sign),
+//   with the temporaries the reference leaves uninitialised taken as zero
+//   (SURVEY.md F6).  This unit is compiled with -ffp-contract=off so the result
+//   is bit-identical to the g++ build of the reference wherever that is defined.
+// MODE 1 (corrected Rusanov): dt/h, all n_real variables.
+#include <cstdio>
+#include "exa_launch.hpp"
+#include "exa_pde.hpp"
+
+namespace exa {
+
+constexpr int MAXV = 8;
+
+template <int DIM, class PDE, int MODE, int CPT, int NT>
+__global__ void __launch_bounds__(NT)
+fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h) {
+    const int S = P + 2 * H;
+    const long vol = (DIM == 3) ? (long)S * S * S : (long)S * S;
+    double* Qp = Q + (long)blockIdx.x * vol * V;
+    const int ncell = (DIM == 3) ? P * P * P : P * P;
+    long st[3];
+    if constexpr (DIM == 3) { st[0] = (long)S * S; st[1] = S; st[2] = 1; }
+    else { st[0] = S; st[1] = 1; st[2] = 0; }
+
+    double nv[CPT][MAXV];
+    long cidx[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+        const int id = threadIdx.x + k * NT;
+        cidx[k] = -1;
+        if (id >= ncell) continue;
+        int co[3];
+        if constexpr (DIM == 3) { co[0] = id / (P * P) + H; co[1] = (id / P) % P + H; co[2] = id % P + H; }
+        else { co[0] = id / P + H; co[1] = id % P + H; co[2] = 0; }
+        const long c = co[0] * st[0] + co[1] * st[1] + co[2] * st[2];
+        cidx[k] = c;
+        double qc[MAXV];
+#pragma unroll
+        for (int v = 0; v < MAXV; v++) qc[v] = v < m ? Qp[c * V + v] : 0.0;
+
+        if constexpr (MODE == 0) {
+            // L6/L7 (test.cpp:60-77): Q_copy = Q_copy - 0.5*F[c+e] + 0.5*F[c-e]; flux rows outside
+            // the normal-direction interior were never computed by L2/L3 (test.cpp:22-23) -> zero.
+            double acc[MAXV];
+#pragma unroll
+            for (int v = 0; v < MAXV; v++) acc[v] = qc[v];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double Fp[MAXV], Fm[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) { Fp[v] = 0.0; Fm[v] = 0.0; }
+                double qP[MAXV], qM[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) {
+                    qP[v] = v < m ? Qp[(c + st[d]) * V + v] : 0.0;
+                    qM[v] = v < m ? Qp[(c - st[d]) * V + v] : 0.0;
+                }
+                if (co[d] + 1 < P + H) PDE::flux_rt(qP, d, Fp);
+                if (co[d] - 1 >= H) PDE::flux_rt(qM, d, Fm);
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) acc[v] = acc[v] - 0.5 * Fp[v] + 0.5 * Fm[v];
+            }
+            // L8/L9 (test.cpp:78-95): variable 0 only, reads the ORIGINAL Q
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double qP[MAXV], qM[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) {
+                    qP[v] = v < m ? Qp[(c + st[d]) * V + v] : 0.0;
+                    qM[v] = v < m ? Qp[(c - st[d]) * V + v] : 0.0;
+                }
+                const double lc = PDE::maxeig(qc, d);
+                const double lp = (co[d] + 1 < P + H) ? PDE::maxeig(qP, d) : 0.0;
+                const double lm = (co[d] - 1 >= H) ? PDE::maxeig(qM, d) : 0.0;
+                const double mp = lp > lc ? lp : lc;     // Functions.cpp:64-66 std::max(*a,*b)
+                const double mm = lm > lc ? lm : lc;
+                const double qp0 = qP[0], qm0 = qM[0], q0 = qc[0];
+                acc[0] = 0.5 * dt * ((-qp0 + q0) * mp + (qm0 - q0) * mm) + acc[0];
+            }
+#pragma unroll
+            for (int v = 0; v < MAXV; v++) nv[k][v] = acc[v];
+        } else {
+            double acc[MAXV];
+#pragma unroll
+            for (int v = 0; v < MAXV; v++) acc[v] = 0.0;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double qpp[MAXV], qmp[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) {
+                    qpp[v] = v < m ? Qp[(c + st[d]) * V + v] : 0.0;
+                    qmp[v] = v < m ? Qp[(c - st[d]) * V + v] : 0.0;
+                }
+                const double* qcp = qc;
+                const double lc = PDE::maxeig(qcp, d);
+                const double sp = fmax(lc, PDE::maxeig(qpp, d));
+                const double sm = fmax(PDE::maxeig(qmp, d), lc);
+                double Fc[MAXV], Fn[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) { Fc[v] = 0.0; Fn[v] = 0.0; }
+                PDE::flux_rt(qcp, d, Fc);
+                PDE::flux_rt(qpp, d, Fn);
+#pragma unroll
+                for (int v = 0; v < MAXV; v++)
+                    if (v < m) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sp * (qpp[v] - qc[v]);
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) Fn[v] = 0.0;
+                PDE::flux_rt(qmp, d, Fn);
+#pragma unroll
+                for (int v = 0; v < MAXV; v++)
+                    if (v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qmp[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < MAXV; v++) nv[k][v] = qc[v] - dt_over_h * acc[v];
+        }
+    }
+    // every read of this patch is done (loads feed the values above) before any write
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+        if (cidx[k] < 0) continue;
+#pragma unroll
+        for (int v = 0; v < MAXV; v++)
+            if (v < m) Qp[cidx[k] * V + v] = nv[k][v];
+    }
+}
+
+template <class PDE>
+__global__ void pde_eval_kernel(int normal, long n, int stride, const double* __restrict__ Q, double* __restrict__ F,
+                                double* __restrict__ lam) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (F) {
+        double f[MAXV];
+#pragma unroll
+        for (int v = 0; v < MAXV; v++) f[v] = 0.0;
+        PDE::flux_rt(&Q[i * stride], normal, f);
+        for (int v = 0; v < PDE::NFLUX && v < stride; v++) F[i * stride + v] = f[v];
+    }
+    if (lam) lam[i] = PDE::maxeig(&Q[i * stride], normal);
+}
+
+template <int DIM, class PDE, int MODE>
+static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, hipStream_t s) {
+    const long ncell = (DIM == 3) ? (long)P * P * P : (long)P * P;
+    const double doh = (MODE == 1) ? dt / h : 0.0;
+    const dim3 grid((unsigned)n_patches);
+    if (ncell <= 256) hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh);
+    else if (ncell <= 1024) hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024>), grid, dim3(1024), 0, s, Q, P, H, m, V, dt, doh);
+    else if (ncell <= 4096) hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024>), grid, dim3(1024), 0, s, Q, P, H, m, V, dt, doh);
+    else {
+        set_error("FV patch with %ld volumes exceeds the 4096 a workgroup keeps in registers", ncell);
+        return -1;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("fv_rusanov launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+template <int DIM, class PDE>
+static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, hipStream_t s) {
+    if (mode == 0) return fv_dispatch<DIM, PDE, 0>(P, H, m, V, n_patches, Q, dt, h, s);
+    return fv_dispatch<DIM, PDE, 1>(P, H, m, V, n_patches, Q, dt, h, s);
+}
+
+int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
+              double h, hipStream_t s) {
+    const int V = n_real + n_aux;
+    if (n_real > MAXV) { set_error("n_real = %d exceeds %d", n_real, MAXV); return -1; }
+    if (n_patches <= 0) return 0;
+    if (dim == 2) {
+        if (pde == 0) return fv_mode<2, EulerRef2D>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
+        if (pde == 1) return fv_mode<2, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
+        if (pde == 2) return fv_mode<2, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
+    } else if (dim == 3) {
+        if (pde == 1) return fv_mode<3, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
+        if (pde == 2) return fv_mode<3, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
+    }
+    set_error("FV Rusanov: no kernel for dim %d, pde %d", dim, pde);
+    return -1;
+}
+
+int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s) {
+    if (n <= 0) return 0;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (pde == 0) hipLaunchKernelGGL((pde_eval_kernel<EulerRef2D>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
+    else if (pde == 1) hipLaunchKernelGGL((pde_eval_kernel<Euler>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
+    else if (pde == 2) hipLaunchKernelGGL((pde_eval_kernel<Advection<1>>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
+    else { set_error("unknown pde %d", pde); return -1; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("pde_eval launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+}  // namespace exa

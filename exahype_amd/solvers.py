@@ -1,0 +1,310 @@
+"""Host-side drivers over the C-ABI: device buffers (torch), streams, the Cartesian
+block partition and the face-trace halo exchange (torch.distributed; backend
+"nccl" is RCCL over xGMI on MI355X).
+
+The reference has no host driver of its own -- its generated `time_step` is called
+from a hand-written `main` (`Unit test/correctness_test.cpp:176-205`) or, by
+intent, from a Peano enclave task (`exahype/printers/CPPPrinter.py:346`).  These
+classes play that role for the HIP kernels: they own nothing numerical.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FV_FAITHFUL, FV_RUSANOV, PDE_ADVECTION, PDE_EULER, PDE_EULER_REF2D, check, darr, larr)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------
+# Finite-Volume Rusanov patch kernel == device form of `time_step` (Unit test/test.h:3)
+# ----------------------------------------------------------------------------------------------
+class FVRusanovKernel:
+    """`time_step(Q, dt)` on MI355X for `n_patches` patches of the reference layout
+    Q[patch][i][j]([k])[var] (halo included)."""
+
+    def __init__(self, dim, patch_size, halo_size, n_real, n_aux, n_patches=1, pde=PDE_EULER_REF2D,
+                 mode=FV_FAITHFUL, device=0):
+        self.lib = _lib.load()
+        self.shape = (n_patches,) + (patch_size + 2 * halo_size,) * dim + (n_real + n_aux,)
+        self.device = device
+        h = C.c_void_p()
+        check(self.lib.exa_fv_plan_create(device, mode, dim, patch_size, halo_size, n_real, n_aux, n_patches, pde,
+                                          C.byref(h)))
+        self._plan = h
+        self.count = self.lib.exa_fv_q_count(h)
+
+    def time_step(self, Q, dt, h=1.0):
+        """In place.  numpy array -> staged through HBM by the library; CUDA tensor -> no copies."""
+        if isinstance(Q, np.ndarray):
+            if Q.dtype != np.float64 or not Q.flags.c_contiguous or Q.size != self.count:
+                raise ValueError("Q must be a C-contiguous float64 array of %d entries" % self.count)
+            check(self.lib.exa_fv_time_step_host(self._plan, Q.ctypes.data_as(C.c_void_p), dt, h))
+            return Q
+        torch = _torch()
+        if not (Q.is_cuda and Q.dtype == torch.float64 and Q.is_contiguous() and Q.numel() == self.count):
+            raise ValueError("Q must be a contiguous float64 CUDA tensor of %d entries" % self.count)
+        check(self.lib.exa_fv_time_step_device(self._plan, C.c_void_p(Q.data_ptr()), dt, h, _stream_ptr()))
+        return Q
+
+    def __del__(self):
+        try:
+            self.lib.exa_fv_plan_destroy(self._plan)
+        except Exception:
+            pass
+
+
+def pde_eval(pde, normal, Q):
+    """Point-wise Flux / maxEigenvalue (Functions.h:2-3) of states Q[n][stride] on the GPU."""
+    torch = _torch()
+    lib = _lib.load()
+    Qd = torch.as_tensor(np.ascontiguousarray(Q), dtype=torch.float64).cuda()
+    n, stride = Qd.shape
+    F = torch.zeros_like(Qd)
+    lam = torch.zeros(n, dtype=torch.float64, device=Qd.device)
+    check(lib.exa_pde_eval_device(pde, normal, n, stride, C.c_void_p(Qd.data_ptr()), C.c_void_p(F.data_ptr()),
+                                  C.c_void_p(lam.data_ptr()), _stream_ptr()))
+    torch.cuda.synchronize()
+    return F.cpu().numpy(), lam.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# Cartesian partition of a regular patch over the ranks of one node
+# ----------------------------------------------------------------------------------------------
+class CartesianPartition:
+    """Process grid for `world` ranks in `dim` dimensions (8 -> 2x2x2, 4 -> 2x2x1,
+    2 -> 2x1x1), rank = row-major index; periodic neighbours."""
+
+    def __init__(self, world, rank, dim, pdims=None):
+        if pdims is None:
+            pdims = [1] * dim
+            w, a = world, 0
+            while w > 1:
+                f = next(p for p in (2, 3, 5, 7, w) if w % p == 0)
+                pdims[a % dim] *= f
+                w //= f
+                a += 1
+        pdims = list(pdims) + [1] * (3 - len(pdims))
+        if int(np.prod(pdims)) != world:
+            raise ValueError("process grid %s does not match world size %d" % (pdims, world))
+        self.world, self.rank, self.dim, self.pdims = world, rank, dim, pdims
+        self.coords = [rank // (pdims[1] * pdims[2]), (rank // pdims[2]) % pdims[1], rank % pdims[2]]
+
+    def rank_of(self, coords):
+        c = [coords[a] % self.pdims[a] for a in range(3)]
+        return (c[0] * self.pdims[1] + c[1]) * self.pdims[2] + c[2]
+
+    def neighbour(self, d, sign):
+        c = list(self.coords)
+        c[d] += sign
+        return self.rank_of(c)
+
+    def partitioned(self, d):
+        return self.pdims[d] > 1
+
+    def shell_and_interior(self, nc):
+        """Disjoint cell boxes: the layers touching a partitioned block face, and the rest."""
+        dim = self.dim
+        lo, hi = [0] * dim, [int(c) for c in nc]
+        shell = []
+        for d in range(dim):
+            if not self.partitioned(d):
+                continue
+            n = hi[d] - lo[d]
+            if n <= 0:
+                break
+            layers = [(lo[d], lo[d] + 1)] if n == 1 else [(lo[d], lo[d] + 1), (hi[d] - 1, hi[d])]
+            for a, b in layers:
+                b_lo, b_hi = list(lo), list(hi)
+                b_lo[d], b_hi[d] = a, b
+                shell.append((b_lo, b_hi))
+            lo[d] += 1
+            hi[d] = max(hi[d] - 1, lo[d])
+        return shell, (lo, hi)
+
+
+class HaloExchange:
+    """Face-trace exchange between neighbouring blocks.  Works on any torch tensors
+    (CUDA with the nccl/RCCL backend; CPU with gloo for the rehearsal tests).
+
+    trace: tensor [dim, 2, nc0, nc1, nc2, TS]; ghosts[d*2+s]: [transverse cells, TS].
+    Message order per peer is fixed so that two messages between the same pair of
+    ranks (process grid extent 2) match without tags as well."""
+
+    def __init__(self, part, nc, ts, device, dtype=None, stage_through_host=False):
+        torch = _torch()
+        self.part, self.nc, self.ts = part, list(nc) + [1] * (3 - len(nc)), ts
+        self.stage = stage_through_host
+        dtype = dtype or torch.float64
+        self.ghost = [None] * 6
+        self.send = [None] * 6
+        for d in range(part.dim):
+            if part.partitioned(d):
+                nt = int(np.prod(self.nc)) // self.nc[d]
+                for s in range(2):
+                    self.ghost[d * 2 + s] = torch.zeros(nt, ts, dtype=dtype, device=device)
+                    self.send[d * 2 + s] = torch.zeros(nt, ts, dtype=dtype, device=device)
+
+    def pack(self, trace):
+        for d in range(self.part.dim):
+            if not self.part.partitioned(d):
+                continue
+            # side 0: L traces of the layer c_d = 0; side 1: R traces of the layer c_d = nc_d - 1
+            lo = trace[d, 0].select(d, 0)
+            hi = trace[d, 1].select(d, self.nc[d] - 1)
+            self.send[d * 2 + 0].copy_(lo.reshape(-1, self.ts))
+            self.send[d * 2 + 1].copy_(hi.reshape(-1, self.ts))
+
+    def start(self):
+        import torch.distributed as dist
+        ops, self._staged = [], []
+        for d in range(self.part.dim):
+            if not self.part.partitioned(d):
+                continue
+            lo_n, hi_n = self.part.neighbour(d, -1), self.part.neighbour(d, +1)
+            s_lo, s_hi = self.send[d * 2 + 0], self.send[d * 2 + 1]
+            g_lo, g_hi = self.ghost[d * 2 + 0], self.ghost[d * 2 + 1]
+            if self.stage:   # gloo rehearsal with device tensors: go through host copies
+                s_lo, s_hi = s_lo.cpu(), s_hi.cpu()
+                h_lo, h_hi = g_lo.cpu(), g_hi.cpu()
+                self._staged += [(g_lo, h_lo), (g_hi, h_hi)]
+                g_lo, g_hi = h_lo, h_hi
+            # my L layer -> low neighbour (its high ghost); my R layer -> high neighbour (its low ghost).
+            # receives are posted in the order the peer sends (its L layer first).
+            ops += [dist.P2POp(dist.isend, s_lo, lo_n, tag=2 * d), dist.P2POp(dist.isend, s_hi, hi_n, tag=2 * d + 1),
+                    dist.P2POp(dist.irecv, g_hi, hi_n, tag=2 * d), dist.P2POp(dist.irecv, g_lo, lo_n, tag=2 * d + 1)]
+        self._reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish(self):
+        for r in self._reqs:
+            r.wait()
+        for dev, host in getattr(self, "_staged", []):
+            dev.copy_(host)
+        self._reqs, self._staged = [], []
+
+    def ghost_ptrs(self):
+        arr = (C.c_void_p * 6)()
+        for f in range(6):
+            arr[f] = self.ghost[f].data_ptr() if self.ghost[f] is not None else None
+        return arr
+
+
+# ----------------------------------------------------------------------------------------------
+# ADER-DG solver on a regular Cartesian block
+# ----------------------------------------------------------------------------------------------
+class AderDgSolver:
+    """One block of `ncells` DG cells of order N-1 on one MI355X.
+
+    u     : CUDA tensor [nc0, nc1, (nc2,) N, N, (N,) n_vars]   (reference AoS layout)
+    trace : CUDA tensor [dim, 2, nc0, nc1, nc2, 2*n_vars*N^(dim-1)]
+
+    With `part` (CartesianPartition) the block is one shard of a periodic global
+    grid: stage A runs on the boundary shell first, the face traces travel over
+    RCCL on a second stream while the interior cells run stage A, stage B follows.
+    """
+
+    def __init__(self, dim, N, ncells, pde=PDE_EULER, n_vars=5, n_picard=-1, dx=None, device=0, part=None,
+                 backend_is_gloo=False):
+        torch = _torch()
+        self.lib = _lib.load()
+        self.dim, self.N, self.nv, self.pde = dim, N, n_vars, pde
+        self.nc = [int(c) for c in ncells]
+        if len(self.nc) != dim:
+            raise ValueError("ncells must have %d entries" % dim)
+        self.dev = torch.device("cuda", device)
+        h = C.c_void_p()
+        check(self.lib.exa_dg_plan_create(device, dim, N, n_vars, pde, n_picard, larr(self.nc), C.byref(h)))
+        self._plan = h
+        self.dx = [float(x) for x in (dx if dx is not None else [1.0 / c for c in self.nc])]
+        self.nf = N ** (dim - 1)
+        self.ts = 2 * n_vars * self.nf
+        self.u = torch.zeros(tuple(self.nc) + (N,) * dim + (n_vars,), dtype=torch.float64, device=self.dev)
+        nc3 = self.nc + [1] * (3 - dim)
+        self.trace = torch.zeros((dim, 2) + tuple(nc3) + (self.ts,), dtype=torch.float64, device=self.dev)
+        assert self.u.numel() == self.lib.exa_dg_dof_count(h) and self.trace.numel() == self.lib.exa_dg_trace_count(h)
+        self.part = part
+        self.halo = None
+        if part is not None and part.world > 1:
+            self.halo = HaloExchange(part, self.nc, self.ts, self.dev, stage_through_host=backend_is_gloo)
+            self.comm_stream = torch.cuda.Stream(device=self.dev)
+            self.shell, self.interior = part.shell_and_interior(self.nc)
+
+    # -- data movement ---------------------------------------------------------------------
+    def upload(self, u_host):
+        torch = _torch()
+        self.u.copy_(torch.as_tensor(np.ascontiguousarray(u_host), dtype=torch.float64).reshape(self.u.shape))
+
+    def download(self):
+        return self.u.cpu().numpy()
+
+    def operators(self):
+        N = self.N
+        out = {k: np.zeros(s) for k, s in (("xi", N), ("w", N), ("D", (N, N)), ("Kxi", (N, N)), ("phiL", N), ("phiR", N),
+                                             ("iK1", (N, N)))}
+        check(self.lib.exa_dg_operators(self._plan, *[out[k].ctypes.data_as(C.c_void_p) for k in
+                                                      ("xi", "w", "D", "Kxi", "phiL", "phiR", "iK1")]))
+        out["N"] = N
+        out["F0"] = out["phiL"].copy()
+        return out
+
+    def work(self):
+        v = [C.c_double() for _ in range(4)]
+        check(self.lib.exa_dg_work(self._plan, *[C.byref(x) for x in v]))
+        return dict(flop_a=v[0].value, flop_b=v[1].value, bytes_a=v[2].value, bytes_b=v[3].value)
+
+    # -- kernels -------------------------------------------------------------------------------
+    def predictor_volume(self, dt, lo=None, hi=None):
+        check(self.lib.exa_dg_predictor_volume_box(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
+                                                   larr(lo) if lo is not None else None, larr(hi) if hi is not None else None,
+                                                   dt, darr(self.dx), _stream_ptr()))
+
+    def riemann_corrector(self, dt, lo=None, hi=None):
+        ghosts = self.halo.ghost_ptrs() if self.halo is not None else None
+        check(self.lib.exa_dg_riemann_corrector(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
+                                                ghosts, larr(lo) if lo is not None else None,
+                                                larr(hi) if hi is not None else None, dt, darr(self.dx), _stream_ptr()))
+
+    def max_eigenvalue(self):
+        torch = _torch()
+        out = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        check(self.lib.exa_dg_max_eigenvalue(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out
+
+    def step(self, dt):
+        """One ADER-DG time step of the block (periodic, or one shard of a periodic grid)."""
+        torch = _torch()
+        if self.halo is None:
+            self.predictor_volume(dt)
+            self.riemann_corrector(dt)
+            return
+        cur = torch.cuda.current_stream(self.dev)
+        for lo, hi in self.shell:                      # boundary shell first ...
+            self.predictor_volume(dt, lo, hi)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.comm_stream):      # ... its traces travel on the comm stream ...
+            self.comm_stream.wait_event(ready)
+            self.halo.pack(self.trace)
+            self.halo.start()
+        lo, hi = self.interior                         # ... while the interior cells run stage A
+        if all(h > l for l, h in zip(lo, hi)):
+            self.predictor_volume(dt, lo, hi)
+        with torch.cuda.stream(self.comm_stream):
+            self.halo.finish()
+        cur.wait_stream(self.comm_stream)
+        self.riemann_corrector(dt)
+
+    def __del__(self):
+        try:
+            self.lib.exa_dg_plan_destroy(self._plan)
+        except Exception:
+            pass

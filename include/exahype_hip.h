@@ -1,0 +1,142 @@
+/*
+ * exahype_hip.h -- C-ABI of libexahype_hip.so, the MI355X (gfx950) drop-in for
+ * the cell-local kernel stack of xdslproject/ExaHyPE.
+ *
+ * Conventions
+ *  - every entry point returns 0 on success, a negative EXA_ERR_* otherwise;
+ *    exa_last_error() gives the thread-local message.  Nothing throws across
+ *    the boundary.
+ *  - plain pointers and sizes only.  `*_dev` pointers are device (HBM)
+ *    addresses owned by the caller; `*_host` pointers are host memory owned by
+ *    the caller.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *  - all arithmetic is IEEE fp64.  Arrays use the reference layout: AoS,
+ *    row-major, variable fastest (reference `exahype/printers/CPPPrinter.py:247-261`).
+ *      FV : Q[patch][i][j]([k])[var], halo included, var < n_real + n_aux
+ *      DG : u[cell][node][var], cell = (cx*ncy+cy)*ncz+cz, node = (i*N+j)*N+k
+ *    axis 0 is the reference's index `i` (normal == 0).
+ *  - a plan is bound to one device; distinct plans are independent; one plan is
+ *    not thread-safe.
+ *
+ * Reference interfaces replaced
+ *  - `void time_step(double* Q, double dt);`                  Unit test/test.h:3
+ *        -> exa_fv_time_step_host / exa_fv_time_step_device (mode EXA_FV_FAITHFUL)
+ *  - `void Flux(const double*, int normal, double* F);`        Unit test/Functions.h:2
+ *    `double maxEigenvalue(const double*, int normal);`        Unit test/Functions.h:3
+ *    `double max(double*, double*);`                           Unit test/Functions.h:4
+ *        -> built-in device PDE terms selected by `pde` (EXA_PDE_*), exercised
+ *           point-wise through exa_pde_eval_device
+ *  - the generated loop nests `Unit test/test.cpp:11-104` (what
+ *    exahype/printers/CPPPrinter.py:84-90 emits per KernelBuilder statement)
+ *        -> the fused FV Rusanov patch kernel behind exa_fv_time_step_*
+ *  - ADER-DG stages (space-time predictor, volume integral, face extrapolation,
+ *    Rusanov Riemann solve, surface corrector): NOT in the reference
+ *    (SURVEY.md F2); the north-star adds them.  -> exa_dg_*
+ */
+#ifndef EXAHYPE_HIP_H
+#define EXAHYPE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXA_OK 0
+#define EXA_ERR_INVALID (-1)     /* bad argument / unsupported configuration */
+#define EXA_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define EXA_ERR_NO_DEVICE (-3)   /* no usable GPU */
+#define EXA_ERR_ALLOC (-4)
+
+/* point-wise PDE term sets (device twins of Unit test/Functions.cpp) */
+#define EXA_PDE_EULER_REF2D 0    /* Functions.cpp:9-62 as compiled by the reference (2-D branch: reads Q[0..3], writes F[0..3]) */
+#define EXA_PDE_EULER 1          /* same arithmetic, (rho, m0, m1, m2, E), gamma = 1.4 */
+#define EXA_PDE_ADVECTION 2      /* linear advection of every variable, a = (1, 0.5, -0.75) */
+
+/* FV Rusanov patch-update modes */
+#define EXA_FV_FAITHFUL 0        /* Unit test/test.cpp:11-104 statement for statement (zero-initialised temporaries) */
+#define EXA_FV_RUSANOV 1         /* corrected Rusanov: dt/h, all n_real variables, dissipative sign */
+
+typedef struct exa_fv_plan exa_fv_plan;
+typedef struct exa_dg_plan exa_dg_plan;
+
+/* ---- library ---------------------------------------------------------------- */
+int exa_version(void);
+const char* exa_last_error(void);
+int exa_device_count(int* count);
+
+/* ---- point-wise PDE terms (Functions.h:2-3) ---------------------------------- */
+/* For n states Q_dev[n][stride] and a normal: F_dev[n][stride] (first n_flux
+ * entries written) and lambda_dev[n].  Either output may be NULL. */
+int exa_pde_eval_device(int pde, int normal, long n, int stride, const double* Q_dev, double* F_dev,
+                        double* lambda_dev, void* stream);
+
+/* ---- Finite-Volume Rusanov patch update (test.h:3) -------------------------- */
+int exa_fv_plan_create(int device, int mode, int dim, int patch_size, int halo_size, int n_real, int n_aux,
+                       long n_patches, int pde, exa_fv_plan** plan);
+int exa_fv_plan_destroy(exa_fv_plan* plan);
+/* doubles in one Q array: n_patches * (patch_size + 2*halo_size)^dim * (n_real + n_aux) */
+long exa_fv_q_count(const exa_fv_plan* plan);
+/* exact analogue of `time_step(Q, dt)`: host AoS array updated in place (interior
+ * volumes only); the library stages it through HBM.  `h` (volume size) is used
+ * by EXA_FV_RUSANOV only. */
+int exa_fv_time_step_host(exa_fv_plan* plan, double* Q_host, double dt, double h);
+/* same on a device-resident array (the hot path: no PCIe in the call) */
+int exa_fv_time_step_device(exa_fv_plan* plan, double* Q_dev, double dt, double h, void* stream);
+
+/* ---- ADER-DG cell kernels ---------------------------------------------------- */
+/* N = order + 1 nodes per axis; n_vars must equal the PDE's variable count (5 for
+ * both Euler sets, any 1..8 for advection); n_picard < 0 selects N iterations,
+ * 0 the single-stage variant (qbar := u, Fbar := f(u)); ncells[dim] is the local
+ * Cartesian block of cells. */
+int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_picard, const long* ncells,
+                       exa_dg_plan** plan);
+int exa_dg_plan_destroy(exa_dg_plan* plan);
+long exa_dg_dof_count(const exa_dg_plan* plan);    /* doubles in u:      ncells * N^dim * n_vars */
+long exa_dg_trace_count(const exa_dg_plan* plan);  /* doubles in traces: dim*2*ncells*2*n_vars*N^(dim-1) */
+long exa_dg_face_count(const exa_dg_plan* plan, int d); /* doubles in one ghost/pack buffer for direction d */
+/* host copies of the reference-element tables the plan uses (each may be NULL):
+ * xi[N] w[N] D[N*N] Kxi[N*N] phiL[N] phiR[N] iK1[N*N] */
+int exa_dg_operators(const exa_dg_plan* plan, double* xi, double* w, double* D, double* Kxi, double* phiL,
+                     double* phiR, double* iK1);
+/* algorithmic work of one stage-A launch (SURVEY.md 8(d) formulas), for rooflines */
+int exa_dg_work(const exa_dg_plan* plan, double* flop_stage_a, double* flop_stage_b, double* bytes_stage_a,
+                double* bytes_stage_b);
+
+/* Stage A, all local cells: space-time predictor (Picard), time averages, volume
+ * integral, face extrapolation.  u_dev is updated IN PLACE to u* ; trace_dev
+ * receives trace[((d*2+side)*ncells + cell)*(2*n_vars*Nf) + (field*n_vars+v)*Nf + y]
+ * (field 0 = time-averaged state, 1 = time-averaged normal flux; side 0 = xi=0). */
+int exa_dg_predictor_volume(exa_dg_plan* plan, double* u_dev, double* trace_dev, double dt, const double* dx,
+                            void* stream);
+/* Stage A restricted to the cell box [lo, hi) of the local block (NULL = whole
+ * block): lets a multi-GPU driver run the block's boundary shell first, start the
+ * face-trace exchange, and overlap it with the interior cells. */
+int exa_dg_predictor_volume_box(exa_dg_plan* plan, double* u_dev, double* trace_dev, const long* lo, const long* hi,
+                                double dt, const double* dx, void* stream);
+/* Stage B on the cell box [lo, hi) of the local block: Rusanov flux on the 2*dim
+ * faces of every cell and the surface corrector; u_dev (holding u*) is updated
+ * in place.  ghost_dev[d*2+0] / [d*2+1] are the neighbour block's traces across
+ * the low / high block face in direction d, layout [transverse cell][2*n_vars*Nf]
+ * (what exa_dg_pack_face produces on the neighbour); a NULL entry means periodic
+ * wrap inside the block. */
+int exa_dg_riemann_corrector(exa_dg_plan* plan, double* u_dev, const double* trace_dev,
+                             const double* const* ghost_dev, const long* lo, const long* hi, double dt,
+                             const double* dx, void* stream);
+/* Copy the outward traces of the block's boundary layer in direction d into a
+ * contiguous buffer: side 0 -> L traces of the cells with c_d == 0 (to be sent
+ * to the low neighbour, which uses it as ghost_dev[d*2+1]); side 1 -> R traces
+ * of the cells with c_d == ncells[d]-1 (-> the high neighbour's ghost_dev[d*2+0]). */
+int exa_dg_pack_face(exa_dg_plan* plan, const double* trace_dev, int d, int side, double* buf_dev, void* stream);
+/* max over all cells/nodes/directions of maxEigenvalue (for a CFL time step);
+ * result is written to *lambda_dev (one double, device). */
+int exa_dg_max_eigenvalue(exa_dg_plan* plan, const double* u_dev, double* lambda_dev, void* stream);
+/* convenience: n_steps full steps on a periodic single block (stage A + stage B) */
+int exa_dg_step_periodic(exa_dg_plan* plan, double* u_dev, double* trace_dev, double dt, const double* dx,
+                         int n_steps, void* stream);
+/* host AoS convenience (allocates/frees HBM internally): one periodic step */
+int exa_dg_step_host(exa_dg_plan* plan, double* u_host, double dt, const double* dx, int n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
