@@ -53,6 +53,13 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # The kernels are launched on torch's streams and on torch-owned HBM, so both must sit on ONE HIP
+    # runtime: torch ships its own libamdhip64 and it has to be the copy already mapped when our
+    # library's DT_NEEDED entry is resolved (two runtimes in one process: the second sees no device).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise ExaHypeHipError(f"{LIB_PATH} is missing (run `python -m exahype_amd.build`); there is no CPU fallback")
