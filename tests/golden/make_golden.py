@@ -83,9 +83,11 @@ def run_example_body(path, first, last, pkg, sub):
 def main():
     pkg, sub = load_reference_slice()
     out = {}
-    k1 = run_example_body(os.path.join(REF, "examples/Batched_stateless.py"), 3, 35, pkg, sub)
-    k2 = run_example_body(os.path.join(REF, "examples/kernel-generator.py"), 3, 45, pkg, sub)
-    for name, k in (("batched_stateless", k1), ("kernel_generator", k2)):
+    # NB: sympy caches Function(name) classes globally, so the type tags of a TypedFunction are shared
+    # by every kernel that names it: dump each kernel's state before the next kernel is built.
+    for name, (path, first, last) in (("batched_stateless", ("examples/Batched_stateless.py", 3, 35)),
+                                      ("kernel_generator", ("examples/kernel-generator.py", 3, 45))):
+        k = run_example_body(os.path.join(REF, path), first, last, pkg, sub)
         st = builder_state(k)
         with open(os.path.join(HERE, f"builder_state_{name}.json"), "w") as f:
             json.dump(st, f, indent=1, sort_keys=True)

@@ -1,0 +1,117 @@
+"""cfg 0 (plumbing, no GPU): the reference's example bodies run unchanged against the new
+KernelBuilder / TypedFunction and produce the state captured from the reference itself."""
+import json
+import os
+
+import pytest
+import sympy
+
+from tests.example_kernels import batched_stateless, builder_state, kernel_generator
+
+
+def _golden(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+@pytest.mark.parametrize("name,make", [
+    ("batched_stateless", lambda KB: batched_stateless(KB)),
+    ("kernel_generator", lambda KB: kernel_generator(KB)),
+    ("3d_p15", lambda KB: batched_stateless(KB, 3, 15, 1, 5, 0, 2)),
+])
+def test_builder_state_equals_reference(golden_dir, name, make):
+    from exahype_amd import KernelBuilder
+    want = _golden(golden_dir, "builder_state_%s.json" % name)
+    got = json.loads(json.dumps(builder_state(make(KernelBuilder))))
+    for key in want:
+        assert got[key] == want[key], key
+    # the PROBE values quoted in SURVEY.md 8(b)
+    if name == "batched_stateless":
+        assert got["directions"] == [-1, -1, 1, -1, 2, -1, 1, -1, 2, 1, 2, 1, 2, -1]
+        assert got["struct_inclusion"] == [2, -1, 0, -1, 0, -1, 0, -1, 0, 1, 1, 1, 1, 2]
+
+
+def test_alias_package_runs_reference_style_script():
+    """`from exahype import KernelBuilder` / `from exahype.printers import ...` as in the reference's examples."""
+    from exahype import KernelBuilder, TypedFunction
+    from exahype.printers import HIPPrinter, MLIRPrinter  # noqa: F401
+    import exahype_amd
+    assert KernelBuilder is exahype_amd.KernelBuilder and TypedFunction is exahype_amd.TypedFunction
+
+
+def test_error_behaviour_matches_reference(golden_dir):
+    from exahype_amd import KernelBuilder
+    want = _golden(golden_dir, "builder_errors.json")
+    for key, (etype, msg) in want.items():
+        with pytest.raises(Exception) as ei:
+            if key == "directional_const_len":
+                KernelBuilder(2, 4, 1, 1, 0).directional_const('n', [0])
+            else:
+                KernelBuilder(n_real=1, n_aux=0, **json.loads(key))
+        assert type(ei.value).__name__ == etype and str(ei.value) == msg
+
+
+def test_return_values_and_seeded_items():
+    from exahype_amd import KernelBuilder
+    k = KernelBuilder(3, 4, 1, 5, 0, n_patches=7)
+    assert [str(i) for i in k.indexes] == ['patch', 'i', 'j', 'k', 'var']
+    for name in ('i', 'j', 'k', 'patch', 'var'):
+        assert isinstance(k.all_items[name], sympy.Idx)
+    for name in ('dim', 'patch_size', 'halo_size', 'n_real', 'n_aux'):
+        assert isinstance(k.all_items[name], sympy.Symbol)
+    assert k.literals[0] == 'int dim = 3;'
+    q = k.item('Q')
+    assert isinstance(q, sympy.IndexedBase) and k.input_types == ['double*'] and k.item_struct['Q'] == 2
+    d = k.const('dt')
+    assert d.is_real and k.inputs == ['dt'] and k.input_types == ['double*', 'double']
+    t = k.directional_item('tmp', struct=False)
+    assert isinstance(t, sympy.IndexedBase) and k.item_struct == {'Q': 2, 'tmp': 0, 'tmp_x': 0, 'tmp_y': 0, 'tmp_z': 0}
+    assert k.const('c', parent=q) == sympy.Symbol('c') and k.parents['c'] == 'Q'
+
+
+def test_typed_function_semantics():
+    from exahype_amd import TypedFunction
+    from sympy.codegen.ast import real
+    F = TypedFunction("SomeTerm")
+    assert F.returnType() is None and F.parameterTypes() is None
+    assert F.returnType(real) == real and F.return_type == real
+    assert F.parameterTypes([real]) == [real]
+    x = sympy.Symbol('x')
+    call = F(x, 2)
+    assert str(type(call)) == "SomeTerm" and type(call).return_type == real      # how single() detects calls
+    assert TypedFunction("SomeTerm") is F                                         # tags are shared by name, as in the reference
+
+
+def test_hip_printer_recognises_rusanov_shape_only():
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import HIPPrinter, UnrecognisedKernel
+    p = HIPPrinter(batched_stateless(KernelBuilder))
+    assert p.scheme == "fv-rusanov-faithful" and p.pde == 0 and "exa_fv_plan_create(dev, 0, 2, 4, 1, 5, 5, 1, 0" in p.code
+    # loop ranges of the generated reference kernel (Unit test/test.cpp:22-23, 81-82, 98-99)
+    k = p.kernel()
+    assert p.loop([k.LHS[2], k.RHS[2]], 1, 3, 0) == [(0, 1), (1, 5), (0, 6), (0, 1)]
+    assert p.loop([k.LHS[11], k.RHS[11]], 1, 3, 1) == [(0, 1), (1, 5), (0, 6), (0, 1)]
+    assert p.loop([k.LHS[13], k.RHS[13]], -1, 3, 2) == [(0, 1), (1, 5), (1, 5), (0, 10)]
+    p3 = HIPPrinter(batched_stateless(KernelBuilder, 3, 15, 1, 5, 0, 2))
+    assert p3.scheme == "fv-rusanov-faithful" and p3.pde == 1
+    with pytest.raises(UnrecognisedKernel):
+        HIPPrinter(kernel_generator(KernelBuilder))                 # Peano CellData flavour: no HIP kernel, says so
+    k2 = batched_stateless(KernelBuilder)
+    k2.single(k2.all_items['Q'][0], 2 * k2.all_items['Q_copy'][0])  # one extra statement -> not the known scheme
+    with pytest.raises(UnrecognisedKernel):
+        HIPPrinter(k2)
+
+
+def test_hip_printer_aderdg_hint_and_file(tmp_path):
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import HIPPrinter
+    k = KernelBuilder(3, 6, 0, 5, 0, n_patches=8)
+    k.item('u')
+    p = HIPPrinter(k, function_name="ader_step", scheme="aderdg")
+    assert p.grid == (2, 2, 2) and p.functionName() == "ader_step" and "dg_stage_a_kernel<3,6>" in p.code
+    p.file(str(tmp_path / "plan.txt"))
+    assert open(tmp_path / "plan.txt").read() == p.code
+    with pytest.raises(ValueError):
+        HIPPrinter(KernelBuilder(3, 6, 1, 5, 0, 8), scheme="aderdg")       # a DG cell has no halo
+    with pytest.raises(NotImplementedError):
+        from exahype_amd.printers import MLIRPrinter
+        MLIRPrinter(k)
