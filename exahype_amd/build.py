@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "lib", "libexahype_hip.so")
 ARCH = "gfx950"
 
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-          "-Wno-pass-failed", "-I", CSRC]
+          "-Wno-pass-failed", "-I", CSRC] + os.environ.get("EXA_EXTRA_FLAGS", "").split()
 
 # (source, object stem, extra flags)
 UNITS = [

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 #include "../../include/exahype_hip.h"
 #include "exa_launch.hpp"
 
@@ -188,11 +189,30 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
     p->ncells = nc;
     p->tab = tab;
     if (build_dg_operators(N, &p->ops) != 0) { delete p; set_error("operator construction failed for N = %d", N); return EXA_ERR_INVALID; }
+    // operator block image in HBM
+    p->ops.dev = nullptr;
+    const size_t ob = tab->ops_image(N, &p->ops, nullptr);
+    std::vector<char> img(ob);
+    tab->ops_image(N, &p->ops, img.data());
+    hipError_t e = hipMalloc(&p->ops.dev, ob);
+    if (e == hipSuccess) e = hipMemcpy(p->ops.dev, img.data(), ob, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->ops.dev) (void)hipFree(p->ops.dev);
+        delete p;
+        set_error("operator block upload failed: %s", hipGetErrorString(e));
+        return EXA_ERR_HIP;
+    }
     *plan = p;
     return EXA_OK;
 }
 
-int exa_dg_plan_destroy(exa_dg_plan* plan) { delete plan; return EXA_OK; }
+int exa_dg_plan_destroy(exa_dg_plan* plan) {
+    if (plan) {
+        if (plan->ops.dev) (void)hipFree(plan->ops.dev);
+        delete plan;
+    }
+    return EXA_OK;
+}
 
 long exa_dg_dof_count(const exa_dg_plan* p) { return p ? p->ncells * lpow(p->N, p->dim) * p->nv : 0; }
 long exa_dg_trace_count(const exa_dg_plan* p) { return p ? (long)p->dim * 2 * p->ncells * 2 * p->nv * lpow(p->N, p->dim - 1) : 0; }

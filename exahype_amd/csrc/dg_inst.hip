@@ -22,12 +22,17 @@ using PDE = Advection<1>;
 constexpr int DIM = EXA_DIM;
 #if EXA_DIM == 3
 constexpr int MAX_N = 6;                       // N = 7, 8 need > 160 KiB of LDS per cell
-constexpr int NT_A = 256;
+constexpr int NT_A = 256;                      // base threads (tasks per phase ~ CPB * N^3 <= 256)
 __host__ __device__ constexpr int cpb_of(int N) { return N == 2 ? 16 : N == 3 ? 8 : N == 4 ? 4 : N == 5 ? 2 : 1; }
+#ifndef EXA_HS
+#define EXA_HS 1
+#endif
+__host__ __device__ constexpr int hs_of(int N) { return (EXA_HS == 2 && N % 2 == 0) ? 2 : 1; }   // 2: row split -> 512 threads, 2 waves/SIMD
 #else
 constexpr int MAX_N = 8;
 constexpr int NT_A = 128;
 __host__ __device__ constexpr int cpb_of(int N) { return (128 / (N * N)) > 0 ? 128 / (N * N) : 1; }
+__host__ __device__ constexpr int hs_of(int) { return 1; }
 #endif
 
 template <int N> static DgOps<N> pack_ops(const DgOpsHost* h) {
@@ -39,6 +44,7 @@ template <int N> static DgOps<N> pack_ops(const DgOpsHost* h) {
         o.phiR[i] = h->phiR[i];
         for (int j = 0; j < N; j++) {
             o.D[i * N + j] = h->D[i * N + j];
+            o.DT[j * N + i] = h->D[i * N + j];
             o.Kxi[i * N + j] = h->Kxi[i * N + j];
             o.T[i * N + j] = h->iK1[i * N + j] * h->w[j];
         }
@@ -46,13 +52,16 @@ template <int N> static DgOps<N> pack_ops(const DgOpsHost* h) {
     return o;
 }
 
+// device image of the operator block for this N (uploaded once per plan by capi.cpp)
+template <int N> static void fill_ops(const DgOpsHost* h, void* dst) { *static_cast<DgOps<N>*>(dst) = pack_ops<N>(h); }
+
 template <int N>
 static int launch_a(const double* u_in, double* u_out, double* trace, long ncells, const CellBox* box, double dt,
                     const double* idx, int n_it, const DgOpsHost* ops, hipStream_t s) {
     constexpr int CPB = cpb_of(N);
     using SA = StageA<DIM, N, PDE, CPB>;
     static_assert(SA::LDS_BYTES <= 160 * 1024, "cell image exceeds the 160 KiB LDS of a gfx950 CU");
-    auto kern = dg_stage_a_kernel<DIM, N, PDE, CPB, NT_A>;
+    auto kern = dg_stage_a_kernel<DIM, N, PDE, CPB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -65,8 +74,8 @@ static int launch_a(const double* u_in, double* u_out, double* trace, long ncell
     }
     if (box->nbox <= 0) return 0;
     const long nblocks = (box->nbox + CPB - 1) / CPB;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT_A), SA::LDS_BYTES, s, u_in, u_out, trace, ncells, *box, dt,
-                       idx[0], idx[1], idx[2], n_it, pack_ops<N>(ops));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(SA::NT), SA::LDS_BYTES, s, u_in, u_out, trace, ncells, *box, dt,
+                       idx[0], idx[1], idx[2], n_it, ops->dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("stage_a launch (dim %d, N %d): %s", DIM, N, hipGetErrorString(e));
@@ -133,6 +142,16 @@ static int stage_b(int N, double* u, const double* trace, const StageBBox* box, 
     return -1;
 }
 
+static size_t ops_image(int N, const DgOpsHost* h, void* dst) {
+    switch (N) {
+#define X(n) case n: if (dst) fill_ops<n>(h, dst); return sizeof(DgOps<n>);
+        EXA_N_CASES(X)
+        EXA_N_CASES_HI(X)
+#undef X
+    }
+    return 0;
+}
+
 static int maxeig(const double* u, long nnodes, double* out, hipStream_t s) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(double), s);
     if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return -2; }
@@ -154,6 +173,7 @@ const DgLaunchTable* EXA_CAT(dg_table_, EXA_DIM, EXA_PDE_ID)() {
     t.stage_a = stage_a;
     t.stage_b = stage_b;
     t.maxeig = maxeig;
+    t.ops_image = ops_image;
     return &t;
 }
 

@@ -16,20 +16,21 @@ template <int N> struct DgOps {
     double w[N];        // Gauss-Legendre weights on [0,1]
     double iw[N];       // 1 / w
     double D[N * N];    // D[i][j]   = phi_j'(xi_i)
+    double DT[N * N];   // DT[j][i]  = D[i][j]  (column j of D contiguous)
     double Kxi[N * N];  // Kxi[i][j] = w_j D[j][i]
     double T[N * N];    // T[l'][l]  = iK1[l'][l] * w_l   (time update; uses iK1*F0 = 1)
     double phiL[N];
     double phiR[N];
 };
 
-// LDS image of one cell: SoA [var][time slab][padded node].  The node index is
-// lexicographic (i slowest) with the i-stride padded so that pencils along any
-// axis hit distinct banks for the 32-lane ds_read_b64 groups
-// (MI355X_MICROARCH.md, LDS table: bank = (addr/4) mod 64 for b64).
+// LDS image of one cell: SoA [var][time slab][node], node index lexicographic (i slowest).
+// 3-D: unpadded -- scripts/lds_stride_search.py shows a padded i-stride makes the k-pencils
+// (stride-N*N+pad lanes) up to 6-way conflicted, while N*N keeps them conflict-free as
+// ds_read_b128 and leaves only a 2-way conflict on the j-pencils (MI355X_MICROARCH.md LDS table).
 template <int DIM, int N> struct Geo {
     static constexpr int NN = ipow(N, DIM);       // nodes per cell
     static constexpr int NF = ipow(N, DIM - 1);   // nodes per face
-    static constexpr int PAD = (DIM == 3) ? 2 : 1;
+    static constexpr int PAD = (DIM == 3) ? 0 : 1;
     static constexpr int SI = ((DIM == 3) ? N * N : N) + PAD;  // stride of axis 0
     static constexpr int SL = N * SI;                           // one (var, slab) image
     static constexpr int NTS = (N > DIM + 1) ? N : DIM + 1;     // slabs per variable

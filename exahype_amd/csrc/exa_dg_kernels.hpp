@@ -31,166 +31,278 @@ template <int I, int E, class F> __device__ inline void static_for(F&& f) {
 // ------------------------------------------------------------------------------------------
 // Stage A
 // ------------------------------------------------------------------------------------------
+// The operator block lives in HBM (plan-owned) and is read through a constant-address-space
+// pointer that is re-materialised ("laundered") at the head of every phase: the loads become
+// s_load_dwordx* next to their use, every matrix entry is an SGPR operand of v_fma_f64, and the
+// compiler cannot hoist all ~150 doubles out of the Picard loop and spill them (v1 spent a
+// quarter of its VALU instructions on v_readlane/v_writelane spill traffic).
+#define EXA_AS4 __attribute__((address_space(4)))
+template <int N> __device__ inline const EXA_AS4 DgOps<N>* ops_here(const void* raw) {
+    unsigned long long a = reinterpret_cast<unsigned long long>(raw);
+    asm volatile("" : "+s"(a));
+    return (const EXA_AS4 DgOps<N>*)a;
+}
+
+// Diagnostic build only (-DEXA_STAMPS): per-phase cycle stamps of wave 0, summed into a debug
+// buffer of their own (never an output element); the production kernel executes no stamp.
+#ifdef EXA_STAMPS
+__device__ unsigned long long g_exa_stamps[48];
+#define EXA_STAMP(slot)                                                                         \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        unsigned long long t_;                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        acc_[slot] += t_ - t_prev_;                                                             \
+        t_prev_ = t_;                                                                           \
+    } while (0)
+#define EXA_STAMP_INIT()                                                                        \
+    unsigned long long t_prev_, acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_)::"memory")
+#define EXA_STAMP_FLUSH()                                                                       \
+    do {                                                                                        \
+        if (bt == 0)                                                                            \
+            for (int k_ = 0; k_ < 12; k_++) atomicAdd(&g_exa_stamps[grp * 12 + k_], acc_[k_]);  \
+    } while (0)
+#else
+#define EXA_STAMP(slot) do { } while (0)
+#define EXA_STAMP_INIT() do { } while (0)
+#define EXA_STAMP_FLUSH() do { } while (0)
+#endif
+
+// Diagnostic ablations (never in the product build): EXA_ABL_NOFMA drops the contraction FMAs,
+// EXA_ABL_NOLDS replaces the Picard loop's LDS reads/writes by register traffic.
+#ifdef EXA_ABL_NOLDS
+#define EXA_LD(i) (ur[0][0] + (double)(i))
+#define EXA_ST(i, val) asm volatile("" ::"v"(val))
+#else
+#define EXA_LD(i) lds[i]
+#define EXA_ST(i, val) lds[i] = (val)
+#endif
+#ifdef EXA_ABL_NOLDS
+#define EXA_ATOMIC_ADD(i, val) asm volatile("" ::"v"(val))
+#else
+#define EXA_ATOMIC_ADD(i, val) (void)__hip_atomic_fetch_add(&lds[i], (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
+#ifdef EXA_ABL_NOFMA
+#define EXA_FMA(acc, a, b) asm volatile("" : "+v"(acc) : "v"(a), "v"(b))
+#else
+#define EXA_FMA(acc, a, b) acc += (a) * (b)
+#endif
+
 template <int DIM, int N, class PDE, int CPB> struct StageA {
     using G = Geo<DIM, N>;
     static constexpr int NV = PDE::NV;
-    static constexpr int NA = PDE::NAUX;
     static constexpr int ASZ = NV * G::NTS * G::SL;         // one q-sized array
-    static constexpr int AXO = 2 * ASZ;                      // aux offset inside a cell image
-    static constexpr int CS = 2 * ASZ + NA * N * G::SL;      // doubles per cell image
+    static constexpr int CS = 3 * ASZ;                       // doubles per cell image: Q, A, B
     static constexpr size_t LDS_BYTES = (size_t)CPB * CS * sizeof(double);
+    static constexpr int TD = CPB * G::NN;                   // pencil tasks per direction (= node tasks)
+    static constexpr int WPD = (TD + 63) / 64;               // waves per direction group
+    static constexpr int NT = DIM * WPD * 64;                // threads per workgroup
 };
 
-template <int DIM, int N, class PDE, int CPB, int NT>
-__global__ void __launch_bounds__(NT)
+// Cell image in LDS: three q-sized arrays Q | A | B, each SoA [var][time slab][node].
+//
+// Thread layout: DIM groups of WPD waves.  In a Picard iteration group d computes the pencils of
+// direction d -- all directions at once, 3 waves per SIMD at N = 6, so one in-order wave's LDS
+// issue/latency hides under the other two (v4, one wave per SIMD: ~6 cycles per VALU and ~8.7 per
+// LDS instruction, serial; dropping every FMA saved 13 % -- profiles/r01_stage_a_stamps.txt).
+// Only plain LDS stores are used for the partial sums (fp64 LDS atomics cost ~17 LDS cycles per
+// wave instruction, v5): x -> A and y -> B directly; z keeps its sums in registers over the barrier
+// and then writes them over Q, which is dead by then.  The time update adds the three, is split by
+// variable between two adjacent lanes, and writes the new iterate back into Q.  The cached scalars
+// of the flux (Euler: 1/rho, p) are recomputed per pencil node instead of stored: VALU has slack,
+// LDS (68 % busy in v5) has not, and the freed 20 KiB are what buys the second sum array.
+template <int DIM, int N, class PDE, int CPB>
+__global__ void __launch_bounds__((StageA<DIM, N, PDE, CPB>::NT))
 dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
-                  long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it, DgOps<N> ops) {
+                  long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
+                  const void* __restrict__ ops_raw) {
     using G = Geo<DIM, N>;
     using SA = StageA<DIM, N, PDE, CPB>;
+    constexpr int NT = SA::NT, TD = SA::TD, GW = SA::WPD * 64;
     constexpr int NV = PDE::NV, NA = PDE::NAUX;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL, NTS = G::NTS;
-    constexpr int ASZ = SA::ASZ, AXO = SA::AXO, CS = SA::CS;
-    constexpr int KMAX = (CPB * NN + NT - 1) / NT;           // node tasks per thread
+    constexpr int ASZ = SA::ASZ, CS = SA::CS;
+    constexpr int NVA = (NV + 1) / 2;                        // variables of the first lane of a T pair
+    constexpr int NJ = (N + 1) / 2;                          // columns of D kept (centro-antisymmetry)
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ long cell_id[CPB];
 
     const int tid = threadIdx.x;
-    const long b0 = (long)blockIdx.x * CPB;       // first box slot of this workgroup
+    EXA_STAMP_INIT();
+    const int grp = __builtin_amdgcn_readfirstlane(tid / GW);   // wave-uniform direction group
+    const int bt = tid - grp * GW;                               // task index inside the group
+    const long b0 = (long)blockIdx.x * CPB;
     const double idx[3] = {idx0, idx1, idx2};
-    // box slot -> cell of the local block (-1: past the end of the box)
-    auto cell_of = [&](int c) -> long { return box.cell(b0 + c); };
+    if (tid < CPB) cell_id[tid] = box.cell(b0 + tid);
 
-    // ---- load u (AoS, coalesced: consecutive lanes -> consecutive nodes), keep it in registers
-    double ur[KMAX][NV];
+    // ---- T-pair role of this thread: node x = tid / 2, variables [v0, v1)
+    const bool t_task = tid < 2 * TD;
+    const int tx = tid >> 1, tg = tid & 1;
+    const int tc = tx / NN, tn = tx - tc * NN;
+    const int toff = tc * CS + G::node_off(tn);
+    const int v0 = tg ? NVA : 0, v1 = tg ? NV : NVA;
+
+    __syncthreads();                                             // cell_id visible
+    // ---- load u (both lanes of a pair read the node: 40 contiguous bytes), q_l := u for every l
+    double ur[NV];
+    {
+        const long cell = t_task ? cell_id[tc] : -1;
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        const int task = tid + k * NT;
-        const int c = task / NN, n = task - c * NN;
-        const long cell = task < CPB * NN ? cell_of(c) : -1;
+        for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + tn) * NV + v] : 1.0;
+        if (t_task && n_it > 0) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) ur[k][v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
-        if (task < CPB * NN && n_it > 0) {
-            const int off = c * CS + G::node_off(n);
-            double a[NA];
-            PDE::aux(ur[k], a);
+            for (int l = 0; l < N; l++)
 #pragma unroll
-            for (int l = 0; l < N; l++) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) lds[off + (v * NTS + l) * SL] = ur[k][v];
-#pragma unroll
-                for (int i = 0; i < NA; i++) lds[off + AXO + (i * N + l) * SL] = a[i];
-            }
+                for (int v = 0; v < NV; v++)
+                    if (v >= v0 && v < v1) lds[toff + (v * NTS + l) * SL] = ur[v];
         }
     }
     __syncthreads();
+    EXA_STAMP(0);
 
     // ---- Picard iterations (A.2):  q <- u - dt * T * sum_d (1/dx_d) D_d f_d(q)
     for (int it = 0; it < n_it; it++) {
+        double s[N][NV];                                         // direction 2 keeps its sums over the barrier
+        int zoff = 0;
         static_for<0, DIM>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
-            constexpr int ps = G::pstride(D);
-            for (int task = tid; task < CPB * N * NF; task += NT) {
-                const int c = task / (N * NF), r = task - c * (N * NF);
+            if (grp == D && bt < TD) {
+                constexpr int ps = G::pstride(D);
+                // D[i][N-1-j] = -D[N-1-i][j]: columns j < NJ suffice (a few SGPRs per j step)
+                const EXA_AS4 double* DTm = ops_here<N>(ops_raw)->DT;
+                const int c = bt / NN, r = bt - c * NN;
                 const int l = r / NF, t = r - l * NF;
                 const int off = c * CS + l * SL + G::pbase(D, t);
-                double F[N][NV];
 #pragma unroll
-                for (int j = 0; j < N; j++) {
-                    double q[NV], a[NA];
+                for (int i = 0; i < N; i++)
 #pragma unroll
-                    for (int v = 0; v < NV; v++) q[v] = lds[off + v * NTS * SL + j * ps];
+                    for (int v = 0; v < NV; v++) s[i][v] = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NA; i++) a[i] = lds[off + AXO + i * N * SL + j * ps];
-                    PDE::template flux<D>(q, a, F[j]);
-                }
+                for (int j = 0; j < NJ; j++) {
+                    const int jm = N - 1 - j;                    // mirror node
+                    double qa[NV], aa[NA], qb[NV], ab[NA], Fa[NV], Fb[NV];
 #pragma unroll
-                for (int i = 0; i < N; i++) {
+                    for (int v = 0; v < NV; v++) qa[v] = EXA_LD(off + v * NTS * SL + j * ps);
+                    if (jm != j) {
 #pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int j = 0; j < N; j++) s += ops.D[i * N + j] * F[j][v];
-                        s *= idx[D];
-                        double* dst = &lds[off + ASZ + v * NTS * SL + i * ps];
-                        if constexpr (D == 0) *dst = s;
-                        else *dst += s;
+                        for (int v = 0; v < NV; v++) qb[v] = EXA_LD(off + v * NTS * SL + jm * ps);
                     }
+                    PDE::aux_fast(qa, aa);
+                    PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
+                    if (jm != j) {
+                        PDE::aux_fast(qb, ab);
+                        PDE::template flux_scaled<D>(qb, ab, idx[D], Fb);
+                    }
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        const double dij = DTm[j * N + i];              // D[i][j]
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            EXA_FMA(s[i][v], dij, Fa[v]);
+                            if (jm != j) EXA_FMA(s[N - 1 - i][v], -dij, Fb[v]);   // D[N-1-i][jm] = -D[i][j]
+                        }
+                    }
+                }
+                if constexpr (D < 2) {
+#pragma unroll
+                    for (int i = 0; i < N; i++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) EXA_ST(off + (1 + D) * ASZ + v * NTS * SL + i * ps, s[i][v]);
+                } else {
+                    zoff = off;
                 }
             }
-            __syncthreads();
         });
-        // time contraction per node, new cached scalars
+        EXA_STAMP(1);
+        __syncthreads();
+        EXA_STAMP(2);
+        if constexpr (DIM == 3) {
+            if (grp == 2 && bt < TD) {                           // every read of Q is done: Q := S_z
+                constexpr int ps = G::pstride(2);
 #pragma unroll
-        for (int k = 0; k < KMAX; k++) {
-            const int task = tid + k * NT;
-            if (task < CPB * NN) {
-                const int c = task / NN, n = task - c * NN;
-                const int off = c * CS + G::node_off(n);
-                double qn[N][NV];
+                for (int i = 0; i < N; i++)
 #pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    double S[N];
+                    for (int v = 0; v < NV; v++) EXA_ST(zoff + v * NTS * SL + i * ps, s[i][v]);
+            }
+            EXA_STAMP(10);
+            __syncthreads();
+            EXA_STAMP(11);
+        }
+        // ---- time contraction, split by variable between the two lanes of a pair
+        if (t_task) {
+            const EXA_AS4 double* Tm = ops_here<N>(ops_raw)->T;
+            double S[NVA][N];
 #pragma unroll
-                    for (int l = 0; l < N; l++) S[l] = lds[off + ASZ + (v * NTS + l) * SL];
+            for (int vv = 0; vv < NVA; vv++)
 #pragma unroll
-                    for (int lp = 0; lp < N; lp++) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int l = 0; l < N; l++) acc += ops.T[lp * N + l] * S[l];
-                        qn[lp][v] = ur[k][v] - dt * acc;
-                        lds[off + (v * NTS + lp) * SL] = qn[lp][v];
+                for (int l = 0; l < N; l++) {
+                    const int o = toff + ((v0 + vv) * NTS + l) * SL;
+                    double x = 0.0;
+                    if (v0 + vv < v1) {
+                        x = EXA_LD(o + ASZ) + EXA_LD(o + 2 * ASZ);
+                        if constexpr (DIM == 3) x += EXA_LD(o);
                     }
+                    S[vv][l] = x;
                 }
 #pragma unroll
-                for (int lp = 0; lp < N; lp++) {
-                    double a[NA];
-                    PDE::aux(qn[lp], a);
+            for (int vv = 0; vv < NVA; vv++) {
+                const double uv = tg ? ur[(NVA + vv) < NV ? NVA + vv : NV - 1] : ur[vv];
 #pragma unroll
-                    for (int i = 0; i < NA; i++) lds[off + AXO + (i * N + lp) * SL] = a[i];
+                for (int lp = 0; lp < N; lp++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int l = 0; l < N; l++) EXA_FMA(acc, Tm[lp * N + l], S[vv][l]);
+                    if (v0 + vv < v1) EXA_ST(toff + ((v0 + vv) * NTS + lp) * SL, uv - dt * acc);
                 }
             }
         }
+        EXA_STAMP(3);
         __syncthreads();
+        EXA_STAMP(4);
     }
 
-    // ---- time averages (A.3) per node: qbar -> B slab 0, Fbar_d -> B slab 1+d, u -> A slab 0
-#pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        const int task = tid + k * NT;
-        if (task < CPB * NN) {
-            const int c = task / NN, n = task - c * NN;
-            const int off = c * CS + G::node_off(n);
-            double qb[NV], Fb[DIM][NV];
+    // ---- time averages (A.3) per node: qbar -> A slab 0, Fbar_d -> A slab 1+d; then u -> Q slab 0
+    {
+        double un[NV], qb[NV], Fb[DIM][NV];
+        const int c = tid / NN, n = tid - c * NN;
+        const int off = c * CS + G::node_off(n);
+        if (tid < TD) {
+            const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
 #pragma unroll
             for (int v = 0; v < NV; v++) qb[v] = 0.0;
 #pragma unroll
             for (int d = 0; d < DIM; d++)
 #pragma unroll
                 for (int v = 0; v < NV; v++) Fb[d][v] = 0.0;
+            const long cell = cell_id[c];
+#pragma unroll
+            for (int v = 0; v < NV; v++) un[v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
             if (n_it > 0) {
 #pragma unroll
                 for (int l = 0; l < N; l++) {
                     double q[NV], a[NA], F[NV];
 #pragma unroll
                     for (int v = 0; v < NV; v++) q[v] = lds[off + (v * NTS + l) * SL];
+                    PDE::aux_fast(q, a);
 #pragma unroll
-                    for (int i = 0; i < NA; i++) a[i] = lds[off + AXO + (i * N + l) * SL];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) qb[v] += ops.w[l] * q[v];
+                    for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[v];
                     static_for<0, DIM>([&](auto dc) {
                         constexpr int D = decltype(dc)::value;
                         PDE::template flux<D>(q, a, F);
 #pragma unroll
-                        for (int v = 0; v < NV; v++) Fb[D][v] += ops.w[l] * F[v];
+                        for (int v = 0; v < NV; v++) Fb[D][v] += wm[l] * F[v];
                     });
                 }
             } else {
                 double a[NA];
-                PDE::aux(ur[k], a);
+                PDE::aux_fast(un, a);
 #pragma unroll
-                for (int v = 0; v < NV; v++) qb[v] = ur[k][v];
+                for (int v = 0; v < NV; v++) qb[v] = un[v];
                 static_for<0, DIM>([&](auto dc) {
                     constexpr int D = decltype(dc)::value;
-                    PDE::template flux<D>(ur[k], a, Fb[D]);
+                    PDE::template flux<D>(un, a, Fb[D]);
                 });
             }
 #pragma unroll
@@ -198,54 +310,59 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
 #pragma unroll
                 for (int d = 0; d < DIM; d++) lds[off + ASZ + (v * NTS + 1 + d) * SL] = Fb[d][v];
-                lds[off + (v * NTS + 0) * SL] = ur[k][v];
+                lds[off + (v * NTS + 0) * SL] = un[v];           // own column of Q only
             }
         }
     }
     __syncthreads();
+    EXA_STAMP(7);
 
     // ---- volume integral + face extrapolation: pencil tasks (c, d, v, t), t fastest
-    for (int task = tid; task < CPB * DIM * NV * NF; task += NT) {
-        const int c = task / (DIM * NV * NF);
-        int r = task - c * (DIM * NV * NF);
-        const int d = r / (NV * NF);
-        r -= d * (NV * NF);
-        const int v = r / NF, t = r - v * NF;
-        const int ps = G::pstride(d);
-        const int off = c * CS + G::pbase(d, t) + v * NTS * SL;
-        double qb[N], Fb[N];
+    {
+        const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+        for (int task = tid; task < CPB * DIM * NV * NF; task += NT) {
+            const int c = task / (DIM * NV * NF);
+            int r = task - c * (DIM * NV * NF);
+            const int d = r / (NV * NF);
+            r -= d * (NV * NF);
+            const int v = r / NF, t = r - v * NF;
+            const int ps = G::pstride(d);
+            const int off = c * CS + G::pbase(d, t) + v * NTS * SL;
+            double qb[N], Fb[N];
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            qb[j] = lds[off + ASZ + j * ps];
-            Fb[j] = lds[off + ASZ + (1 + d) * SL + j * ps];
-        }
-        const double sc = dt * idx[d];
+            for (int j = 0; j < N; j++) {
+                qb[j] = lds[off + ASZ + j * ps];
+                Fb[j] = lds[off + ASZ + (1 + d) * SL + j * ps];
+            }
+            const double sc = dt * idx[d];
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            double s = 0.0;
+            for (int i = 0; i < N; i++) {
+                double sv = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; j++) s += ops.Kxi[i * N + j] * Fb[j];
-            lds[off + (1 + d) * SL + i * ps] = sc * ops.iw[i] * s;
-        }
-        double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
+                for (int j = 0; j < N; j++) sv += o->Kxi[i * N + j] * Fb[j];
+                lds[off + (1 + d) * SL + i * ps] = sc * o->iw[i] * sv;
+            }
+            double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            qL += ops.phiL[j] * qb[j];
-            qR += ops.phiR[j] * qb[j];
-            FL += ops.phiL[j] * Fb[j];
-            FR += ops.phiR[j] * Fb[j];
-        }
-        const long cell = cell_of(c);
-        if (cell >= 0) {
-            double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
-            double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
-            tl[(0 * NV + v) * NF + t] = qL;
-            tl[(1 * NV + v) * NF + t] = FL;
-            tr[(0 * NV + v) * NF + t] = qR;
-            tr[(1 * NV + v) * NF + t] = FR;
+            for (int j = 0; j < N; j++) {
+                qL += o->phiL[j] * qb[j];
+                qR += o->phiR[j] * qb[j];
+                FL += o->phiL[j] * Fb[j];
+                FR += o->phiR[j] * Fb[j];
+            }
+            const long cell = cell_id[c];
+            if (cell >= 0) {
+                double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
+                double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
+                tl[(0 * NV + v) * NF + t] = qL;
+                tl[(1 * NV + v) * NF + t] = FL;
+                tr[(0 * NV + v) * NF + t] = qR;
+                tr[(1 * NV + v) * NF + t] = FR;
+            }
         }
     }
     __syncthreads();
+    EXA_STAMP(8);
 
     // ---- u* = u + sum_d vol_d, written AoS (coalesced)
     for (int task = tid; task < CPB * NN * NV; task += NT) {
@@ -255,9 +372,11 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         double us = lds[off];
 #pragma unroll
         for (int d = 0; d < DIM; d++) us += lds[off + (1 + d) * SL];
-        const long cell = cell_of(c);
+        const long cell = cell_id[c];
         if (cell >= 0) u_out[cell * (NN * NV) + e] = us;
     }
+    EXA_STAMP(9);
+    EXA_STAMP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------

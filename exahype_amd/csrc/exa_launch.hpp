@@ -11,6 +11,7 @@ struct DgOpsHost {
     int N;
     double xi[MAXN], w[MAXN], D[MAXN * MAXN], Kxi[MAXN * MAXN], phiL[MAXN], phiR[MAXN], iK1[MAXN * MAXN],
         K1[MAXN * MAXN];
+    void* dev;     // DgOps<N> image in HBM (read by the kernels through the constant address space)
 };
 // dg_operators_host.cpp: Gauss-Legendre nodes by Newton, barycentric derivative
 // matrix, K1 inverse by Gauss-Jordan, all in long double.
@@ -29,6 +30,7 @@ struct DgLaunchTable {
     int (*stage_b)(int N, double* u, const double* trace, const StageBBox* box, long ncells, double dt,
                    const double* idx, const DgOpsHost* ops, hipStream_t s);
     int (*maxeig)(const double* u, long nnodes, double* out, hipStream_t s);
+    size_t (*ops_image)(int N, const DgOpsHost* h, void* dst);   // dst == nullptr: size only
 };
 // returns nullptr when (dim, pde) is not built
 const DgLaunchTable* dg_launch_table(int dim, int pde);

@@ -1,0 +1,37 @@
+// Diagnostic: per-phase cycle shares of dg_stage_a_kernel<3,6,Euler> (wave 0 of every workgroup).
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DEXA_STAMPS -I exahype_amd/csrc scripts/stamps_stage_a.hip -o scripts/stamps_stage_a
+#include <cstdio>
+#include <vector>
+#include "exa_dg_kernels.hpp"
+using namespace exa;
+int main() {
+    constexpr int N = 6, DIM = 3, CPB = 1;
+    using SA = StageA<DIM, N, Euler, CPB>;
+    const long nc = 32, ncells = nc * nc * nc;
+    const long ndof = ncells * 216 * 5, ntr = 3 * 2 * ncells * 2 * 5 * 36;
+    std::vector<double> h(ndof);
+    for (long i = 0; i < ndof; i++) { int v = i % 5; h[i] = v == 0 ? 1.0 + 0.1 * ((i * 7919) % 100) / 100.0 : (v == 4 ? 2.5 + 0.1 * ((i * 104729) % 100) / 100.0 : 0.1 * (((i * 31) % 100) / 100.0 - 0.5)); }
+    double *u, *tr; void* ops;
+    hipMalloc(&u, ndof * 8); hipMalloc(&tr, ntr * 8); hipMalloc(&ops, sizeof(DgOps<N>));
+    hipMemcpy(u, h.data(), ndof * 8, hipMemcpyHostToDevice);
+    DgOps<N> o{};   // the values do not matter for timing shares; keep them finite and small
+    for (int i = 0; i < N; i++) { o.w[i] = 1.0 / N; o.iw[i] = N; o.phiL[i] = 0.1; o.phiR[i] = 0.1; for (int j = 0; j < N; j++) { o.D[i*N+j] = 0.01*(i-j); o.DT[j*N+i] = 0.01*(i-j); o.Kxi[i*N+j] = 0.01; o.T[i*N+j] = 0.01; } }
+    hipMemcpy(ops, &o, sizeof(o), hipMemcpyHostToDevice);
+    auto kern = dg_stage_a_kernel<DIM, N, Euler, CPB>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SA::LDS_BYTES);
+    CellBox box; for (int d = 0; d < 3; d++) { box.nc[d] = nc; box.lo[d] = 0; box.nb[d] = nc; } box.nbox = ncells;
+    for (int rep = 0; rep < 2; rep++) {
+        unsigned long long z[48] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_exa_stamps), z, sizeof(z));
+        hipLaunchKernelGGL(kern, dim3(ncells), dim3(SA::NT), SA::LDS_BYTES, 0, u, u, tr, ncells, box, 1e-5, nc * 1.0, nc * 1.0, nc * 1.0, N, ops);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(z, HIP_SYMBOL(g_exa_stamps), sizeof(z));
+        const char* names[12] = {"load+init", "D work", "D barrier", "T work", "T barrier", "aux work", "aux barrier", "avg (F1)", "vol+traces (F2)", "store (F3)", "z store", "z barrier"};
+        if (rep == 0) continue;
+        printf("cycles per cell, first wave of each direction group (x, y, z):\n");
+        for (int k = 0; k < 12; k++) printf("   %-18s %9.0f %9.0f %9.0f\n", names[k], (double)z[k] / ncells, (double)z[12 + k] / ncells, (double)z[24 + k] / ncells);
+        double tot = 0; for (int k = 0; k < 12; k++) tot += z[k];
+        printf("   total              %9.0f\n", tot / ncells);
+    }
+    return 0;
+}
