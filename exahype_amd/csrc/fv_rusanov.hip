@@ -26,11 +26,17 @@ constexpr int MAXV = 8;
 
 template <int DIM, class PDE, int MODE, int CPT, int NT>
 __global__ void __launch_bounds__(NT)
-fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h) {
+fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h, long n_patches,
+                  int ppb) {
+    // `ppb` small patches share one workgroup (the reference's 4x4 patch has 16 volumes: one patch per
+    // 256-thread workgroup would idle 94 % of the lanes); large patches use ppb = 1 and CPT volumes per thread.
     const int S = P + 2 * H;
     const long vol = (DIM == 3) ? (long)S * S * S : (long)S * S;
-    double* Qp = Q + (long)blockIdx.x * vol * V;
     const int ncell = (DIM == 3) ? P * P * P : P * P;
+    const int pl = (CPT == 1) ? (int)threadIdx.x / ncell : 0;            // patch slot of this thread
+    const long patch = (long)blockIdx.x * ppb + pl;
+    const bool live = pl < ppb && patch < n_patches;
+    double* Qp = Q + (live ? patch : 0) * vol * V;
     long st[3];
     if constexpr (DIM == 3) { st[0] = (long)S * S; st[1] = S; st[2] = 1; }
     else { st[0] = S; st[1] = 1; st[2] = 0; }
@@ -39,9 +45,9 @@ fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt,
     long cidx[CPT];
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
-        const int id = threadIdx.x + k * NT;
+        const int id = (CPT == 1) ? (int)threadIdx.x - pl * ncell : (int)threadIdx.x + k * NT;
         cidx[k] = -1;
-        if (id >= ncell) continue;
+        if (!live || id >= ncell) continue;
         int co[3];
         if constexpr (DIM == 3) { co[0] = id / (P * P) + H; co[1] = (id / P) % P + H; co[2] = id % P + H; }
         else { co[0] = id / P + H; co[1] = id % P + H; co[2] = 0; }
@@ -157,10 +163,15 @@ template <int DIM, class PDE, int MODE>
 static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, hipStream_t s) {
     const long ncell = (DIM == 3) ? (long)P * P * P : (long)P * P;
     const double doh = (MODE == 1) ? dt / h : 0.0;
-    const dim3 grid((unsigned)n_patches);
-    if (ncell <= 256) hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh);
-    else if (ncell <= 1024) hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024>), grid, dim3(1024), 0, s, Q, P, H, m, V, dt, doh);
-    else if (ncell <= 4096) hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024>), grid, dim3(1024), 0, s, Q, P, H, m, V, dt, doh);
+    if (ncell <= 256) {
+        const int ppb = (int)(256 / ncell);
+        const dim3 grid((unsigned)((n_patches + ppb - 1) / ppb));
+        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb);
+    } else if (ncell <= 1024) {
+        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+    } else if (ncell <= 4096) {
+        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+    }
     else {
         set_error("FV patch with %ld volumes exceeds the 4096 a workgroup keeps in registers", ncell);
         return -1;
