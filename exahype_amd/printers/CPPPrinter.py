@@ -1,0 +1,172 @@
+"""CPPPrinter -- text-compatible twin of the reference's C++ printer
+(`exahype/printers/CPPPrinter.py:45-354`), so scripts that target the Peano tool-chain
+(`examples/kernel-generator.py:48`) keep producing the same `time_step` source from this package.
+
+Pinned by tests/golden/cppprinter_*.txt (captured from the reference at HEAD).  The reference's text
+is reproduced WITH its defects (`&&Q_copy`, `Flux(...) = None;`,
+`patch - 1` offsets, name matching by substring) -- this class is a compatibility shim, not the
+execution path; the MI355X path is HIPPrinter.
+
+Own structure: statements are rendered by three small passes (loop plan -> index flattening ->
+name qualification) instead of the reference's recursive string surgery.  Not reproduced: the
+reference's `parse()` post-pass (`CPPPrinter.py:278-316`), which only acts when the first input is
+used as an object (`<input0>.member`); no known kernel triggers it.
+"""
+from __future__ import annotations
+
+import re
+
+from sympy import tensor
+
+from .CodePrinter import CodePrinter
+
+_PEANO_INCLUDES = (
+    "exahype2/UserInterface.h", "observers/CreateGrid.h", "observers/CreateGridAndConvergeLoadBalancing.h",
+    "observers/CreateGridButPostponeRefinement.h", "observers/InitGrid.h", "observers/PlotSolution.h",
+    "observers/TimeStep.h", "peano4/peano.h", "repositories/DataRepository.h", "repositories/SolverRepository.h",
+    "repositories/StepRepository.h", "tarch/accelerator/accelerator.h", "tarch/accelerator/Device.h",
+    "tarch/logging/CommandLineLogger.h", "tarch/logging/Log.h", "tarch/logging/LogFilter.h",
+    "tarch/logging/Statistics.h", "tarch/multicore/Core.h", "tarch/multicore/multicore.h",
+    "tarch/multicore/otter.h", "tarch/NonCriticalAssertions.h", "tarch/timing/Measurement.h",
+    "tarch/timing/Watch.h", "tasks/FVRusanovSolverEnclaveTask.h", "toolbox/loadbalancing/loadbalancing.h")
+
+_OFFSET_MARKS = ('i +', 'i -', 'j +', 'j -', 'k +', 'k -')
+
+
+class CPPPrinter(CodePrinter):
+    def __init__(self: CPPPrinter, kernel, function_name: str = "time_step"):
+        super().__init__(kernel, function_name=function_name)
+        k = kernel
+        out = [self._signature()]
+        if k.literals:
+            out += ['\t%s\n' % lit for lit in k.literals] + ['\n']
+        temps = [str(it) for it in k.all_items.values()
+                 if isinstance(it, tensor.indexed.IndexedBase) and str(it) not in k.inputs and str(it) not in k.parents]
+        full = k.patch_size + 2 * k.halo_size
+        for name in temps:
+            extent = '*'.join([str(k.n_patches)] + [str(full)] * k.dim)
+            if k.item_struct[name] != 0:
+                extent += '*%d' % (k.n_real + k.n_aux if name in k.items else k.n_real)
+            out.append('\tdouble *%s = new double[%s];\n' % (name, extent))
+        out += ['\tdouble %s;\n' % k.all_items[c] for c in k.directional_consts] + ['\n']
+        for lhs, rhs, direction, span in zip(k.LHS, k.RHS, k.directions, k.struct_inclusion):
+            if str(lhs) in k.directional_consts:
+                out.append('\t%s = %s;\n' % (lhs, rhs))
+            else:
+                out.append(self.loop([lhs, rhs], direction, k.dim + 1, span))
+        out += ['\n'] + ['\tdelete[] %s;\n' % name for name in temps] + ['}\n']
+        self.code = ''.join(out)
+
+    # -- pieces ---------------------------------------------------------------------------------------
+    def _signature(self):
+        k = self.kernel()
+        if k.input_types:
+            args = ['%s %s' % (k.input_types[0], k.inputs[0])]
+        elif k.inputs:
+            args = ['auto %s' % k.inputs[0]]
+        else:
+            args = []
+        args += ['%s %s' % (k.input_types[i], k.inputs[i]) for i in range(1, len(k.inputs))]
+        return 'void %s(%s) {\n' % (self.functionName(), ', '.join(args))
+
+    def _ranges(self, expr, direction, span):
+        """[lo, hi) per loop level (patch, axes..., var) -- the reference's rule at HEAD
+        (`CPPPrinter.py:110-137`)."""
+        k = self.kernel()
+        interior = (k.halo_size, k.patch_size + k.halo_size)
+        full = (0, k.patch_size + 2 * k.halo_size)
+        text = (str(expr[0]), str(expr[1]))
+        has_offset = any(m in text[0] or m in text[1] for m in _OFFSET_MARKS)
+        last = expr[0] == k.LHS[-1]
+        out = [(0, k.n_patches)]
+        for level in range(1, k.dim + 1):
+            if last or direction == -1 or direction != level or has_offset:
+                out.append(interior)
+            else:
+                out.append(full)
+        spans = [v for name, v in k.item_struct.items() if name in str(expr)] + [span]
+        out.append({0: (0, 1), 1: (0, k.n_real), 2: (0, k.n_real + k.n_aux)}[min(spans)])
+        return out
+
+    def loop(self, expr, direction: int, below: int, struct_inclusion: int):
+        """One loop nest for one statement (text)."""
+        k = self.kernel()
+        rng = self._ranges(expr, direction, struct_inclusion)
+        lines, depth = [], 1
+        for idx, (lo, hi) in zip(k.indexes, rng):
+            if str(idx) == 'var' and hi == 1:
+                continue
+            lines.append('%sfor (int %s = %d; %s < %d; %s++) {\n' % ('\t' * depth, idx, lo, idx, hi, idx))
+            depth += 1
+        stmt = self.Cppify(expr[0])
+        if not (isinstance(expr[1], str) and expr[1] == ''):
+            stmt += ' = ' + self.Cppify(expr[1])
+        if rng[-1][1] == 1:
+            stmt = stmt.replace(' + var', '')
+        lines.append('%s%s;\n' % ('\t' * depth, stmt))
+        for d in range(depth - 1, 0, -1):
+            lines.append('%s}\n' % ('\t' * d))
+        return ''.join(lines)
+
+    def heritage(self, text: str):
+        """Qualify every alphabetic word that has a parent: `parent.word`, or `parent::word` when the
+        parent is a namespace (ends with ':')."""
+        parents = self.kernel().parents
+
+        def qualify(m):
+            w = m.group(0)
+            if w not in parents:
+                return w
+            p = parents[w]
+            return p + w if p.endswith(':') else p + '.' + w
+        return re.sub(r'[A-Za-z]+', qualify, text)
+
+    def Cppify(self, item):
+        """`name[patch, i + 1, j, var]` -> `name[s0*patch + s1*(i + 1) + s2*j + var]` with the AoS strides,
+        `&` in front of array arguments of calls, parent qualification."""
+        k = self.kernel()
+        pieces = re.split(r'(\[|\])', str(item))
+        out, in_call, owner, in_index = [], False, '', False
+        arrays = k.items + k.directional_items
+        for piece in pieces:
+            if piece == '':
+                continue
+            if piece == '[':
+                out.append('[')
+                in_index = True
+            elif in_index:
+                in_index = False
+                out.append(self._flatten(owner, piece))
+            else:
+                if ')' in piece:
+                    in_call = False
+                owner = piece
+                if any(f in piece for f in k.functions):
+                    in_call = True
+                if in_call:
+                    for name in arrays:
+                        if name in piece:
+                            piece = piece.replace(name, '&' + name)
+                out.append(self.heritage(piece))
+        return ''.join(out)
+
+    def _flatten(self, owner: str, indices: str):
+        k = self.kernel()
+        first = next(name for name in k.item_struct if name in owner)        # substring match, dict order
+        leap = {0: 1, 1: k.n_real, 2: k.n_real + k.n_aux}[k.item_struct[first]]
+        size = k.patch_size if (len(k.items) > 1 and first == k.items[1]) else k.patch_size + 2 * k.halo_size
+        strides = [leap * size ** 2, leap * size, leap]
+        if k.dim == 3:
+            strides = [leap * size ** 3] + strides
+        terms = []
+        for n, idx in enumerate(i.strip() for i in indices.split(',')):
+            t = ('%d*' % strides[n]) if n < len(strides) else ''
+            terms.append(t + (idx if idx in k.all_items else '(%s)' % idx))
+        return ' + '.join(terms)
+
+    def file(self: CPPPrinter, file_name: str = 'test.cpp', header_file_name: str = None):
+        text = '\n' + ''.join('#include "%s"\n' % h for h in _PEANO_INCLUDES) + '\n\n\n' + self.code
+        if header_file_name is not None:
+            text = '#include "%s"\n\n' % header_file_name + text
+        self.code = text
+        super().file(file_name, header_file_name)

@@ -115,3 +115,30 @@ def test_hip_printer_aderdg_hint_and_file(tmp_path):
     with pytest.raises(NotImplementedError):
         from exahype_amd.printers import MLIRPrinter
         MLIRPrinter(k)
+
+
+@pytest.mark.parametrize("name,make", [
+    ("batched_stateless", lambda KB: batched_stateless(KB)),
+    ("kernel_generator", lambda KB: kernel_generator(KB)),
+    ("3d_p15", lambda KB: batched_stateless(KB, 3, 15, 1, 5, 0, 2)),
+])
+def test_cpp_printer_text_equals_reference(golden_dir, name, make):
+    """the compatibility CPPPrinter reproduces the reference's generated text (HEAD)."""
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import CPPPrinter
+    want = open(os.path.join(golden_dir, "cppprinter_%s.txt" % name)).read()
+    p = CPPPrinter(make(KernelBuilder))
+    assert p.code == want
+    assert p.functionName() == "time_step" and p.kernel().dim in (2, 3)
+
+
+def test_cpp_printer_file_prepends_includes(tmp_path):
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import CPPPrinter
+    p = CPPPrinter(batched_stateless(KernelBuilder), function_name="step")
+    body = p.code
+    assert body.startswith("void step(double* dt) {")
+    p.file(str(tmp_path / "k.cpp"), header_file_name="Functions.h")
+    text = open(tmp_path / "k.cpp").read()
+    assert text.startswith('#include "Functions.h"\n\n\n#include "exahype2/UserInterface.h"\n') and text.endswith(body)
+    assert text.count("#include") == 26
