@@ -73,7 +73,14 @@ __device__ unsigned long long g_exa_stamps[48];
 // Diagnostic ablations (never in the product build): EXA_ABL_NOFMA drops the contraction FMAs,
 // EXA_ABL_NOLDS replaces the Picard loop's LDS reads/writes by register traffic.
 #ifdef EXA_ABL_NOLDS
-#define EXA_LD(i) (ur[0][0] + (double)(i))
+#define EXA_LD2(i) make_double2(ur[0] + (double)(i), ur[1])
+#define EXA_ST2(i, a, b) asm volatile("" ::"v"(a), "v"(b))
+#else
+#define EXA_LD2(i) (*reinterpret_cast<const double2*>(&lds[i]))
+#define EXA_ST2(i, a, b) *reinterpret_cast<double2*>(&lds[i]) = make_double2((a), (b))
+#endif
+#ifdef EXA_ABL_NOLDS
+#define EXA_LD(i) (ur[0] + (double)(i))
 #define EXA_ST(i, val) asm volatile("" ::"v"(val))
 #else
 #define EXA_LD(i) lds[i]
@@ -108,8 +115,8 @@ template <int DIM, int N, class PDE, int CPB> struct StageA {
 // issue/latency hides under the other two (v4, one wave per SIMD: ~6 cycles per VALU and ~8.7 per
 // LDS instruction, serial; dropping every FMA saved 13 % -- profiles/r01_stage_a_stamps.txt).
 // Only plain LDS stores are used for the partial sums (fp64 LDS atomics cost ~17 LDS cycles per
-// wave instruction, v5): x -> A and y -> B directly; z keeps its sums in registers over the barrier
-// and then writes them over Q, which is dead by then.  The time update adds the three, is split by
+// wave instruction, v5): y -> A and z -> B directly; x -- the conflict-free, fastest group -- keeps its
+// sums in registers over the barrier and then writes them over Q, which is dead by then.  The time update adds the three, is split by
 // variable between two adjacent lanes, and writes the new iterate back into Q.  The cached scalars
 // of the flux (Euler: 1/rho, p) are recomputed per pencil node instead of stored: VALU has slack,
 // LDS (68 % busy in v5) has not, and the freed 20 KiB are what buys the second sum array.
@@ -138,8 +145,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     if (tid < CPB) cell_id[tid] = box.cell(b0 + tid);
 
     // ---- T-pair role of this thread: node x = tid / 2, variables [v0, v1)
-    const bool t_task = tid < 2 * TD;
-    const int tx = tid >> 1, tg = tid & 1;
+    // (the two lanes of a pair sit 32 lanes apart: every 16/32-lane LDS group then sees consecutive nodes)
+    const int tx = ((tid >> 6) << 5) | (tid & 31), tg = (tid >> 5) & 1;
+    const bool t_task = tx < TD;
     const int tc = tx / NN, tn = tx - tc * NN;
     const int toff = tc * CS + G::node_off(tn);
     const int v0 = tg ? NVA : 0, v1 = tg ? NV : NVA;
@@ -164,7 +172,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 
     // ---- Picard iterations (A.2):  q <- u - dt * T * sum_d (1/dx_d) D_d f_d(q)
     for (int it = 0; it < n_it; it++) {
-        double s[N][NV];                                         // direction 2 keeps its sums over the barrier
+        double s[N][NV];                                         // direction 0 keeps its sums over the barrier
         int zoff = 0;
         static_for<0, DIM>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
@@ -179,15 +187,30 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 for (int i = 0; i < N; i++)
 #pragma unroll
                     for (int v = 0; v < NV; v++) s[i][v] = 0.0;
+                // pencils along the contiguous axis (ps == 1, N even): 16-byte LDS accesses -- the pencil
+                // bases are 3*t 16-byte units apart, a permutation mod 16 for every hardware lane group, so
+                // ds_read_b128 / ds_write_b128 are conflict-free where 8-byte accesses are 2-way conflicted
+                constexpr bool WIDE = (ps == 1) && (N % 2 == 0);
+                double qw[WIDE ? N : 1][NV];
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+#pragma unroll
+                        for (int jj = 0; jj < N / 2; jj++) {
+                            const double2 t2 = EXA_LD2(off + v * NTS * SL + 2 * jj);
+                            qw[2 * jj][v] = t2.x;
+                            qw[2 * jj + 1][v] = t2.y;
+                        }
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     const int jm = N - 1 - j;                    // mirror node
                     double qa[NV], aa[NA], qb[NV], ab[NA], Fa[NV], Fb[NV];
 #pragma unroll
-                    for (int v = 0; v < NV; v++) qa[v] = EXA_LD(off + v * NTS * SL + j * ps);
+                    for (int v = 0; v < NV; v++) qa[v] = WIDE ? qw[WIDE ? j : 0][v] : EXA_LD(off + v * NTS * SL + j * ps);
                     if (jm != j) {
 #pragma unroll
-                        for (int v = 0; v < NV; v++) qb[v] = EXA_LD(off + v * NTS * SL + jm * ps);
+                        for (int v = 0; v < NV; v++) qb[v] = WIDE ? qw[WIDE ? jm : 0][v] : EXA_LD(off + v * NTS * SL + jm * ps);
                     }
                     PDE::aux_fast(qa, aa);
                     PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
@@ -205,11 +228,18 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         }
                     }
                 }
-                if constexpr (D < 2) {
+                if constexpr (D > 0 && WIDE) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+#pragma unroll
+                        for (int ii = 0; ii < N / 2; ii++)
+                            EXA_ST2(off + D * ASZ + v * NTS * SL + 2 * ii, s[2 * ii][v], s[2 * ii + 1][v]);
+                } else
+                if constexpr (D > 0) {
 #pragma unroll
                     for (int i = 0; i < N; i++)
 #pragma unroll
-                        for (int v = 0; v < NV; v++) EXA_ST(off + (1 + D) * ASZ + v * NTS * SL + i * ps, s[i][v]);
+                        for (int v = 0; v < NV; v++) EXA_ST(off + D * ASZ + v * NTS * SL + i * ps, s[i][v]);
                 } else {
                     zoff = off;
                 }
@@ -218,9 +248,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         EXA_STAMP(1);
         __syncthreads();
         EXA_STAMP(2);
-        if constexpr (DIM == 3) {
-            if (grp == 2 && bt < TD) {                           // every read of Q is done: Q := S_z
-                constexpr int ps = G::pstride(2);
+        {
+            if (grp == 0 && bt < TD) {                           // every read of Q is done: Q := S_x
+                constexpr int ps = G::pstride(0);
 #pragma unroll
                 for (int i = 0; i < N; i++)
 #pragma unroll
@@ -241,8 +271,8 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                     const int o = toff + ((v0 + vv) * NTS + l) * SL;
                     double x = 0.0;
                     if (v0 + vv < v1) {
-                        x = EXA_LD(o + ASZ) + EXA_LD(o + 2 * ASZ);
-                        if constexpr (DIM == 3) x += EXA_LD(o);
+                        x = EXA_LD(o) + EXA_LD(o + ASZ);
+                        if constexpr (DIM == 3) x += EXA_LD(o + 2 * ASZ);
                     }
                     S[vv][l] = x;
                 }
