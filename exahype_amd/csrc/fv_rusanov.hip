@@ -24,10 +24,14 @@ namespace exa {
 
 constexpr int MAXV = 8;
 
-template <int DIM, class PDE, int MODE, int CPT, int NT>
+// STAGE = true (small patches): the workgroup's `ppb` patches are one contiguous block of HBM; it is
+// copied into LDS with coalesced 16-byte loads and the stencil reads LDS (the AoS stencil reads straight
+// from HBM touch ~40 cache lines per wave instruction: 1.7 TB/s; staged: see DESIGN.md 4.3).
+template <int DIM, class PDE, int MODE, int CPT, int NT, bool STAGE>
 __global__ void __launch_bounds__(NT)
 fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h, long n_patches,
                   int ppb) {
+    extern __shared__ __attribute__((aligned(16))) double fv_lds[];
     // `ppb` small patches share one workgroup (the reference's 4x4 patch has 16 volumes: one patch per
     // 256-thread workgroup would idle 94 % of the lanes); large patches use ppb = 1 and CPT volumes per thread.
     const int S = P + 2 * H;
@@ -36,7 +40,25 @@ fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt,
     const int pl = (CPT == 1) ? (int)threadIdx.x / ncell : 0;            // patch slot of this thread
     const long patch = (long)blockIdx.x * ppb + pl;
     const bool live = pl < ppb && patch < n_patches;
-    double* Qp = Q + (live ? patch : 0) * vol * V;
+    double* Qg = Q + (live ? patch : 0) * vol * V;              // this thread's patch in HBM (writes)
+    const double* Qp = Qg;                                       // ... and where the stencil reads it
+    if constexpr (STAGE) {
+        const long first = (long)blockIdx.x * ppb;
+        const long npatch = (n_patches - first < ppb) ? n_patches - first : ppb;
+        const long total = npatch * vol * V;                     // doubles in this workgroup's block
+        const double* src = Q + first * vol * V;
+        const bool al16 = ((reinterpret_cast<unsigned long long>(src) & 15) == 0);
+        if (al16) {
+            const double2* s2 = reinterpret_cast<const double2*>(src);
+            double2* d2 = reinterpret_cast<double2*>(fv_lds);
+            for (long i = threadIdx.x; i < total / 2; i += NT) d2[i] = s2[i];
+            if ((total & 1) && threadIdx.x == 0) fv_lds[total - 1] = src[total - 1];
+        } else {
+            for (long i = threadIdx.x; i < total; i += NT) fv_lds[i] = src[i];
+        }
+        __syncthreads();
+        Qp = fv_lds + (long)(live ? pl : 0) * vol * V;
+    }
     long st[3];
     if constexpr (DIM == 3) { st[0] = (long)S * S; st[1] = S; st[2] = 1; }
     else { st[0] = S; st[1] = 1; st[2] = 0; }
@@ -135,12 +157,43 @@ fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt,
     }
     // every read of this patch is done (loads feed the values above) before any write
     __syncthreads();
+    bool rows = false;
+    if constexpr (STAGE) {
+        // auxiliary variables present (V even, rows 16-byte aligned): results go into the LDS copy first, then
+        // whole interior rows (P*V contiguous doubles) stream back with coalesced 16-byte stores
+        rows = ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (V % 2 == 0) && (V > m);
+    }
+    if (rows) {
+        double* Ql = fv_lds + (long)(live ? pl : 0) * vol * V;
 #pragma unroll
-    for (int k = 0; k < CPT; k++) {
-        if (cidx[k] < 0) continue;
+        for (int k = 0; k < CPT; k++) {
+            if (cidx[k] < 0) continue;
 #pragma unroll
-        for (int v = 0; v < MAXV; v++)
-            if (v < m) Qp[cidx[k] * V + v] = nv[k][v];
+            for (int v = 0; v < MAXV; v++)
+                if (v < m) Ql[cidx[k] * V + v] = nv[k][v];
+        }
+        __syncthreads();
+        const long first = (long)blockIdx.x * ppb;
+        const long npatch = (n_patches - first < ppb) ? n_patches - first : ppb;
+        const int rows_pp = (DIM == 3) ? P * P : P;                  // interior rows per patch
+        const int r2 = P * V / 2;                                    // double2 per row
+        double* dst = Q + first * vol * V;
+        for (long e = threadIdx.x; e < npatch * rows_pp * r2; e += NT) {
+            const long row = e / r2;
+            const int x = (int)(e - row * r2);
+            const long pp = row / rows_pp;
+            const int rr = (int)(row - pp * rows_pp);
+            const long o = pp * vol * V + ((DIM == 3) ? ((long)(rr / P + H) * S * S + (long)(rr % P + H) * S + H) : ((long)(rr + H) * S + H)) * V;
+            reinterpret_cast<double2*>(dst + o)[x] = reinterpret_cast<const double2*>(fv_lds + o)[x];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPT; k++) {
+            if (cidx[k] < 0) continue;
+#pragma unroll
+            for (int v = 0; v < MAXV; v++)
+                if (v < m) Qg[cidx[k] * V + v] = nv[k][v];
+        }
     }
 }
 
@@ -163,14 +216,24 @@ template <int DIM, class PDE, int MODE>
 static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, hipStream_t s) {
     const long ncell = (DIM == 3) ? (long)P * P * P : (long)P * P;
     const double doh = (MODE == 1) ? dt / h : 0.0;
+    const int S = P + 2 * H;
+    const long pvol = (DIM == 3) ? (long)S * S * S : (long)S * S;
     if (ncell <= 256) {
         const int ppb = (int)(256 / ncell);
         const dim3 grid((unsigned)((n_patches + ppb - 1) / ppb));
-        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb);
+        const size_t lds = (size_t)ppb * pvol * V * sizeof(double);
+        if (lds <= 64 * 1024)       // staged: up to two workgroups per CU keep HBM requests in flight
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb);
+        else
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, false>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb);
     } else if (ncell <= 1024) {
-        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+        const size_t lds = (size_t)pvol * V * sizeof(double);
+        if (lds <= 64 * 1024)
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+        else
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
     } else if (ncell <= 4096) {
-        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
     }
     else {
         set_error("FV patch with %ld volumes exceeds the 4096 a workgroup keeps in registers", ncell);
