@@ -73,6 +73,20 @@ static int launch_a(const double* u_in, double* u_out, double* trace, long ncell
         attr_set = true;
     }
     if (box->nbox <= 0) return 0;
+    if (n_it == 0) {            // single-stage variant: lean LDS image, many cells per workgroup
+        constexpr int NT1 = 256;
+        constexpr int NNc = ipow(N, DIM);
+        constexpr int CPB1 = (NT1 / NNc) > 0 ? NT1 / NNc : 1;
+        const long nb1 = (box->nbox + CPB1 - 1) / CPB1;
+        hipLaunchKernelGGL((dg_stage_a_single_kernel<DIM, N, PDE, CPB1, NT1>), dim3((unsigned)nb1), dim3(NT1), 0, s, u_in, u_out,
+                           trace, ncells, *box, dt, idx[0], idx[1], idx[2], ops->dev);
+        hipError_t e1 = hipGetLastError();
+        if (e1 != hipSuccess) {
+            set_error("stage_a (single stage) launch (dim %d, N %d): %s", DIM, N, hipGetErrorString(e1));
+            return -2;
+        }
+        return 0;
+    }
     const long nblocks = (box->nbox + CPB - 1) / CPB;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(SA::NT), SA::LDS_BYTES, s, u_in, u_out, trace, ncells, *box, dt,
                        idx[0], idx[1], idx[2], n_it, ops->dev);

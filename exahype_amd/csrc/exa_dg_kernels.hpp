@@ -410,6 +410,117 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 }
 
 // ------------------------------------------------------------------------------------------
+// Stage A, single-stage variant (n_picard = 0: qbar := u, Fbar := f(u); BASELINE configs[1])
+// ------------------------------------------------------------------------------------------
+// No space-time image: per cell only qbar and Fbar_d live in LDS ((1+DIM) node arrays per variable,
+// the volume term overwrites Fbar_d pencil by pencil), so many cells share a workgroup and several
+// workgroups share a CU -- this variant is HBM-bound (B_A = 16 m N^d + 32 d m N^(d-1) bytes per cell).
+template <int DIM, int N, class PDE, int CPB, int NT>
+__global__ void __launch_bounds__(NT)
+dg_stage_a_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
+                         long ncells, CellBox box, double dt, double idx0, double idx1, double idx2,
+                         const void* __restrict__ ops_raw) {
+    using G = Geo<DIM, N>;
+    constexpr int NV = PDE::NV, NA = PDE::NAUX;
+    constexpr int NN = G::NN, NF = G::NF, SL = G::SL;
+    constexpr int CS = (1 + DIM) * NV * SL;                  // doubles per cell image
+    constexpr int KMAX = (CPB * NN + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) double lds[CPB * CS];
+    __shared__ long cell_id[CPB];
+    const int tid = threadIdx.x;
+    const long b0 = (long)blockIdx.x * CPB;
+    const double idx[3] = {idx0, idx1, idx2};
+    if (tid < CPB) cell_id[tid] = box.cell(b0 + tid);
+    __syncthreads();
+
+    double ur[KMAX][NV];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int task = tid + k * NT;
+        if (task < CPB * NN) {
+            const int c = task / NN, n = task - c * NN;
+            const long cell = cell_id[c];
+            const int off = c * CS + G::node_off(n);
+            double a[NA], F[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) ur[k][v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
+            PDE::aux_fast(ur[k], a);
+#pragma unroll
+            for (int v = 0; v < NV; v++) lds[off + v * SL] = ur[k][v];
+            static_for<0, DIM>([&](auto dc) {
+                constexpr int D = decltype(dc)::value;
+                PDE::template flux<D>(ur[k], a, F);
+#pragma unroll
+                for (int v = 0; v < NV; v++) lds[off + ((1 + D) * NV + v) * SL] = F[v];
+            });
+        }
+    }
+    __syncthreads();
+    {
+        const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+        for (int task = tid; task < CPB * DIM * NV * NF; task += NT) {
+            const int c = task / (DIM * NV * NF);
+            int r = task - c * (DIM * NV * NF);
+            const int d = r / (NV * NF);
+            r -= d * (NV * NF);
+            const int v = r / NF, t = r - v * NF;
+            const int ps = G::pstride(d);
+            const int off = c * CS + G::pbase(d, t);
+            double qb[N], Fb[N];
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                qb[j] = lds[off + v * SL + j * ps];
+                Fb[j] = lds[off + ((1 + d) * NV + v) * SL + j * ps];
+            }
+            const double sc = dt * idx[d];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                double sv = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; j++) sv += o->Kxi[i * N + j] * Fb[j];
+                lds[off + ((1 + d) * NV + v) * SL + i * ps] = sc * o->iw[i] * sv;   // own pencil only
+            }
+            double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                qL += o->phiL[j] * qb[j];
+                qR += o->phiR[j] * qb[j];
+                FL += o->phiL[j] * Fb[j];
+                FR += o->phiR[j] * Fb[j];
+            }
+            const long cell = cell_id[c];
+            if (cell >= 0) {
+                double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
+                double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
+                tl[(0 * NV + v) * NF + t] = qL;
+                tl[(1 * NV + v) * NF + t] = FL;
+                tr[(0 * NV + v) * NF + t] = qR;
+                tr[(1 * NV + v) * NF + t] = FR;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int task = tid + k * NT;
+        if (task < CPB * NN) {
+            const int c = task / NN, n = task - c * NN;
+            const long cell = cell_id[c];
+            const int off = c * CS + G::node_off(n);
+            if (cell >= 0) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    double us = ur[k][v];
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) us += lds[off + ((1 + d) * NV + v) * SL];
+                    u_out[(cell * NN + n) * NV + v] = us;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Stage B
 // ------------------------------------------------------------------------------------------
 struct StageBArgs {
