@@ -101,9 +101,13 @@ static int launch_a(const double* u_in, double* u_out, double* trace, long ncell
 template <int N>
 static int launch_b(double* u, const double* trace, const StageBBox* box, long ncells, double dt, const double* idx,
                     const DgOpsHost* ops, hipStream_t s) {
-    constexpr int NT_B = 256;
-    constexpr int NFN = 2 * DIM * ipow(N, DIM - 1);
-    constexpr int CPB = (NT_B / NFN) > 0 ? NT_B / NFN : 1;
+    constexpr int NFc = ipow(N, DIM - 1);
+    constexpr bool SHUFFLE = pow2ceil(NFc) == NFc;                    // face fills its lane segment
+    // shuffle variant: one lane segment per face, all faces of the workgroup's cells in one pass;
+    // dense variant: (cell, face, node) tasks packed over 256 lanes
+    constexpr int PER = 2 * DIM * (SHUFFLE ? pow2ceil(NFc) : NFc);
+    constexpr int CPB = PER >= 256 ? 1 : 256 / PER;
+    constexpr int NT_B = SHUFFLE ? ((CPB * PER + 63) / 64) * 64 : 256;
     StageBArgs A;
     long nbox = 1;
     for (int d = 0; d < 3; d++) {
@@ -115,8 +119,12 @@ static int launch_b(double* u, const double* trace, const StageBBox* box, long n
     for (int f = 0; f < 6; f++) A.ghost[f] = box->ghost[f];
     if (nbox <= 0) return 0;
     const long nblocks = (nbox + CPB - 1) / CPB;
-    hipLaunchKernelGGL((dg_stage_b_kernel<DIM, N, PDE, CPB, NT_B>), dim3((unsigned)nblocks), dim3(NT_B), 0, s, u, trace, A,
-                       ncells, nbox, dt, idx[0], idx[1], idx[2], pack_ops<N>(ops));
+    if constexpr (SHUFFLE)
+        hipLaunchKernelGGL((dg_stage_b_kernel<DIM, N, PDE, CPB, NT_B>), dim3((unsigned)nblocks), dim3(NT_B), 0, s, u, trace, A,
+                           ncells, nbox, dt, idx[0], idx[1], idx[2], pack_ops<N>(ops));
+    else
+        hipLaunchKernelGGL((dg_stage_b_dense_kernel<DIM, N, PDE, CPB, NT_B>), dim3((unsigned)nblocks), dim3(NT_B), 0, s, u, trace,
+                           A, ncells, nbox, dt, idx[0], idx[1], idx[2], pack_ops<N>(ops));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("stage_b launch (dim %d, N %d): %s", DIM, N, hipGetErrorString(e));

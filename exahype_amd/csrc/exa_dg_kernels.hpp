@@ -529,9 +529,137 @@ struct StageBArgs {
     const double* ghost[6];
 };
 
+__host__ __device__ constexpr int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// Faces are laid out on aligned lane segments of GS = pow2ceil(Nf) lanes, 64/GS faces per wave pass:
+// the face-wide maximum eigenvalue (A.4) is a segmented butterfly of wavefront shuffles, no LDS, no
+// barrier; only the Rusanov fluxes go through LDS to reach the node-major corrector update.
 template <int DIM, int N, class PDE, int CPB, int NT>
 __global__ void __launch_bounds__(NT)
 dg_stage_b_kernel(double* __restrict__ u, const double* __restrict__ trace, StageBArgs A, long ncells, long nbox,
+                  double dt, double idx0, double idx1, double idx2, DgOps<N> ops) {
+    using G = Geo<DIM, N>;
+    constexpr int NV = PDE::NV;
+    constexpr int NN = G::NN, NF = G::NF;
+    constexpr int NFACE = 2 * DIM;
+    constexpr int TS = 2 * NV * NF;                     // doubles per (cell, d, side) trace
+    constexpr int GS = pow2ceil(NF);                    // lanes per face segment
+    static_assert(GS <= 64, "a face must fit one wavefront");
+    constexpr int FPB = NT / GS;                        // faces per workgroup pass
+    constexpr int NFC = CPB * NFACE;                    // faces of this workgroup
+    constexpr int KB = (NFC + FPB - 1) / FPB;
+    __shared__ double fs[CPB * NFACE * NF * NV];
+    __shared__ double cL[DIM][N], cR[DIM][N];
+
+    const int tid = threadIdx.x;
+    const long b0 = (long)blockIdx.x * CPB;
+    const double idx[3] = {idx0, idx1, idx2};
+    // (compile-time index into the kernarg-resident operator block: stays in SGPRs)
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (tid == i) {
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                cL[d][i] = dt * idx[d] * ops.iw[i] * ops.phiL[i];
+                cR[d][i] = dt * idx[d] * ops.iw[i] * ops.phiR[i];
+            }
+        }
+    }
+
+    // cell of box slot c
+    auto cell_of = [&](int c, long* cc) -> long {
+        long b = b0 + c;
+        if (b >= nbox) b = nbox - 1;
+        long cz = 0, cy, cx;
+        if constexpr (DIM == 3) {
+            cz = b % A.nb[2];
+            b /= A.nb[2];
+        }
+        cy = b % A.nb[1];
+        cx = b / A.nb[1];
+        cc[0] = A.lo[0] + cx;
+        cc[1] = A.lo[1] + cy;
+        cc[2] = (DIM == 3) ? A.lo[2] + cz : 0;
+        return (cc[0] * A.nc[1] + cc[1]) * A.nc[2] + cc[2];
+    };
+
+    const int seg = tid / GS, y = tid - seg * GS;
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+        const int face = seg + k * FPB;                 // (c, f) flattened
+        const bool ok = face < NFC && y < NF;
+        double qm[NV], qp[NV], Fm[NV], Fp[NV];
+        double lam = 0.0;
+        int d = 0;
+        if (ok) {
+            const int c = face / NFACE, f = face - c * NFACE;
+            d = f >> 1;
+            const int side = f & 1;
+            long cc[3];
+            const long cell = cell_of(c, cc);
+            long cst[3];
+            cst[2] = 1;
+            cst[1] = A.nc[2];
+            cst[0] = A.nc[1] * A.nc[2];
+            // transverse cell index on the block face (lexicographic over the other axes)
+            long tcell;
+            if constexpr (DIM == 3) tcell = d == 0 ? cc[1] * A.nc[2] + cc[2] : (d == 1 ? cc[0] * A.nc[2] + cc[2] : cc[0] * A.nc[1] + cc[1]);
+            else tcell = d == 0 ? cc[1] : cc[0];
+            const double *pm, *pp;
+            if (side == 0) {   // minus = left neighbour's R trace, plus = own L trace
+                pp = trace + (((long)d * 2 + 0) * ncells + cell) * TS;
+                if (cc[d] > 0) pm = trace + (((long)d * 2 + 1) * ncells + cell - cst[d]) * TS;
+                else if (A.ghost[d * 2 + 0]) pm = A.ghost[d * 2 + 0] + tcell * TS;
+                else pm = trace + (((long)d * 2 + 1) * ncells + cell + (A.nc[d] - 1) * cst[d]) * TS;
+            } else {           // minus = own R trace, plus = right neighbour's L trace
+                pm = trace + (((long)d * 2 + 1) * ncells + cell) * TS;
+                if (cc[d] < A.nc[d] - 1) pp = trace + (((long)d * 2 + 0) * ncells + cell + cst[d]) * TS;
+                else if (A.ghost[d * 2 + 1]) pp = A.ghost[d * 2 + 1] + tcell * TS;
+                else pp = trace + (((long)d * 2 + 0) * ncells + cell - (A.nc[d] - 1) * cst[d]) * TS;
+            }
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                qm[v] = pm[v * NF + y];
+                qp[v] = pp[v * NF + y];
+                Fm[v] = pm[(NV + v) * NF + y];
+                Fp[v] = pp[(NV + v) * NF + y];
+            }
+            lam = fmax(PDE::maxeig(qm, d), PDE::maxeig(qp, d));
+        }
+        // face-wide maximum: segmented butterfly over the GS lanes of the face (inactive lanes carry 0)
+#pragma unroll
+        for (int o = GS / 2; o > 0; o >>= 1) lam = fmax(lam, __shfl_xor(lam, o, GS));
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+                fs[(face * NF + y) * NV + v] = 0.5 * (Fm[v] + Fp[v]) - 0.5 * lam * (qp[v] - qm[v]);
+        }
+    }
+    __syncthreads();
+    for (int task = tid; task < CPB * NN * NV; task += NT) {
+        const int c = task / (NN * NV), e = task - c * (NN * NV);
+        if (b0 + c >= nbox) continue;
+        const int n = e / NV, v = e - n * NV;
+        long cc[3];
+        const long cell = cell_of(c, cc);
+        double un = u[cell * (NN * NV) + e];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            const int i = G::coord(n, d), yy = G::face_index(n, d);
+            const double fR = fs[((c * NFACE + d * 2 + 1) * NF + yy) * NV + v];
+            const double fL = fs[((c * NFACE + d * 2 + 0) * NF + yy) * NV + v];
+            un -= cR[d][i] * fR - cL[d][i] * fL;
+        }
+        u[cell * (NN * NV) + e] = un;
+    }
+}
+
+// Dense variant for face sizes that are not a power of two (Nf = 9, 25, 36, 49): tasks (cell, face, node)
+// packed densely over the lanes, face-wide maximum through a small LDS array (a 36-node face on a 64-lane
+// segment would idle 44 % of the lanes of the trace loads).
+template <int DIM, int N, class PDE, int CPB, int NT>
+__global__ void __launch_bounds__(NT)
+dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace, StageBArgs A, long ncells, long nbox,
                   double dt, double idx0, double idx1, double idx2, DgOps<N> ops) {
     using G = Geo<DIM, N>;
     constexpr int NV = PDE::NV;
