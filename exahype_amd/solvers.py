@@ -308,3 +308,107 @@ class AderDgSolver:
             self.lib.exa_dg_plan_destroy(self._plan)
         except Exception:
             pass
+
+
+# ----------------------------------------------------------------------------------------------
+# The steps either side of the FV kernel: halo fill + time loop on a regular grid
+# ----------------------------------------------------------------------------------------------
+def fill_halos_periodic(Q, grid, dim, patch_size, halo_size):
+    """Fill the halo layers of every patch of a periodic Cartesian grid of patches from its neighbours'
+    interior layers (the role Peano's enclave task plays before it calls the generated `time_step`,
+    reference `exahype/printers/CPPPrinter.py:346`).
+
+    Q: tensor (torch, any device) or numpy array [g0, g1, (g2,) S, S, (S,) V], updated in place.
+    Axis by axis over the full transverse range, so edges and corners are filled too."""
+    P, H, S = patch_size, halo_size, patch_size + 2 * halo_size
+    is_np = isinstance(Q, np.ndarray)
+    roll = (lambda a, s, ax: np.roll(a, s, axis=ax)) if is_np else (lambda a, s, ax: a.roll(s, dims=ax))
+    assert tuple(Q.shape[:dim]) == tuple(grid) and all(s == S for s in Q.shape[dim:2 * dim])
+    for a in range(dim):
+        lo = [slice(None)] * Q.ndim
+        hi = [slice(None)] * Q.ndim
+        src_hi = [slice(None)] * Q.ndim
+        src_lo = [slice(None)] * Q.ndim
+        lo[dim + a] = slice(0, H)                     # low halo  <- high interior layers of the low neighbour
+        src_hi[dim + a] = slice(P, P + H)
+        hi[dim + a] = slice(P + H, S)                 # high halo <- low interior layers of the high neighbour
+        src_lo[dim + a] = slice(H, 2 * H)
+        Q[tuple(lo)] = roll(Q[tuple(src_hi)], 1, a)
+        Q[tuple(hi)] = roll(Q[tuple(src_lo)], -1, a)
+    return Q
+
+
+class FVPatchGrid:
+    """A periodic Cartesian grid of FV patches resident in HBM, advanced by the fused Rusanov kernel:
+    halo fill -> `time_step` for every patch -> ... ; dt from the CFL condition when asked."""
+
+    def __init__(self, dim, grid, patch_size, halo_size=1, n_real=5, n_aux=0, pde=PDE_EULER, mode=FV_RUSANOV,
+                 length=1.0, device=0):
+        torch = _torch()
+        self.dim, self.grid, self.P, self.H = dim, tuple(int(g) for g in grid), patch_size, halo_size
+        self.n_real, self.n_aux, self.pde = n_real, n_aux, pde
+        self.h = length / (self.grid[0] * patch_size)                  # volume size
+        n_patches = int(np.prod(self.grid))
+        self.kernel = FVRusanovKernel(dim, patch_size, halo_size, n_real, n_aux, n_patches, pde, mode, device)
+        S = patch_size + 2 * halo_size
+        self.Q = torch.zeros(self.grid + (S,) * dim + (n_real + n_aux,), dtype=torch.float64,
+                             device=torch.device("cuda", device))
+        self.time = 0.0
+
+    def set_interior(self, values):
+        """values: [g.., P.., V] (numpy or tensor)."""
+        torch = _torch()
+        H, P = self.H, self.P
+        sl = (slice(None),) * self.dim + (slice(H, H + P),) * self.dim
+        self.Q[sl] = torch.as_tensor(np.asarray(values), dtype=torch.float64).to(self.Q.device)
+
+    def interior(self):
+        H, P = self.H, self.P
+        return self.Q[(slice(None),) * self.dim + (slice(H, H + P),) * self.dim].cpu().numpy()
+
+    def max_eigenvalue(self):
+        lib = _lib.load()
+        torch = _torch()
+        flat = self.Q.reshape(-1, self.n_real + self.n_aux)
+        lam = torch.zeros(flat.shape[0], dtype=torch.float64, device=self.Q.device)
+        best = 0.0
+        for d in range(self.dim):
+            check(lib.exa_pde_eval_device(self.pde, d, flat.shape[0], flat.shape[1], C.c_void_p(flat.data_ptr()), None,
+                                          C.c_void_p(lam.data_ptr()), _stream_ptr()))
+            best = max(best, float(lam.max()))
+        return best
+
+    def step(self, dt):
+        fill_halos_periodic(self.Q, self.grid, self.dim, self.P, self.H)
+        self.kernel.time_step(self.Q, dt, self.h)
+        self.time += dt
+
+    def run(self, t_end, cfl=0.4, max_steps=1000000):
+        steps = 0
+        while self.time < t_end * (1 - 1e-14) and steps < max_steps:
+            fill_halos_periodic(self.Q, self.grid, self.dim, self.P, self.H)
+            dt = min(cfl * self.h / (self.dim * self.max_eigenvalue()), t_end - self.time)
+            self.kernel.time_step(self.Q, dt, self.h)
+            self.time += dt
+            steps += 1
+        return steps
+
+
+def _dg_run(self, t_end, cfl=0.4, max_steps=1000000):
+    """Time loop with the CFL step dt = cfl * min(dx) / ((2p+1) * d * lambda_max); with a partition the
+    maximum eigenvalue is reduced over the ranks (the only true collective of the scheme)."""
+    torch = _torch()
+    t, steps = 0.0, 0
+    while t < t_end * (1 - 1e-14) and steps < max_steps:
+        lam = self.max_eigenvalue()
+        if self.part is not None and self.part.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(lam, op=dist.ReduceOp.MAX)
+        dt = min(cfl * min(self.dx) / ((2 * self.N - 1) * self.dim * float(lam[0])), t_end - t)
+        self.step(dt)
+        t += dt
+        steps += 1
+    return steps
+
+
+AderDgSolver.run = _dg_run
