@@ -42,6 +42,8 @@ template <int N> static DgOps<N> pack_ops(const DgOpsHost* h) {
         o.iw[i] = 1.0 / h->w[i];
         o.phiL[i] = h->phiL[i];
         o.phiR[i] = h->phiR[i];
+        o.Tsum[i] = 0.0;
+        for (int j = 0; j < N; j++) o.Tsum[i] += h->iK1[i * N + j] * h->w[j];
         for (int j = 0; j < N; j++) {
             o.D[i * N + j] = h->D[i * N + j];
             o.DT[j * N + i] = h->D[i * N + j];

@@ -19,6 +19,7 @@ template <int N> struct DgOps {
     double DT[N * N];   // DT[j][i]  = D[i][j]  (column j of D contiguous)
     double Kxi[N * N];  // Kxi[i][j] = w_j D[j][i]
     double T[N * N];    // T[l'][l]  = iK1[l'][l] * w_l   (time update; uses iK1*F0 = 1)
+    double Tsum[N];     // sum_l T[l'][l]                  (iteration 0: the iterate is constant in time)
     double phiL[N];
     double phiR[N];
 };

@@ -174,14 +174,25 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     for (int it = 0; it < n_it; it++) {
         double s[N][NV];                                         // direction 0 keeps its sums over the barrier
         int zoff = 0;
+        bool did_x = false;
         static_for<0, DIM>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
-            if (grp == D && bt < TD) {
+            // iteration 0: the iterate is constant in time, so every time slab has the same sums -- only the
+            // l = 0 pencils are computed (the time update below then uses the row sums of T).  They are
+            // packed on W0 waves per direction at the front of the workgroup, i.e. on different SIMDs
+            // (the first waves of the three groups would share one SIMD and serialise).
+            constexpr int W0 = (CPB * NF + 63) / 64;
+            const int wave = tid >> 6;
+            const int k0 = (wave - D * W0) * 64 + (tid & 63);      // iteration-0 task of this lane for direction D
+            const bool mine = it > 0 ? (grp == D && bt < TD) : (wave >= D * W0 && wave < (D + 1) * W0 && k0 < CPB * NF);
+            if (mine) {
                 constexpr int ps = G::pstride(D);
                 // D[i][N-1-j] = -D[N-1-i][j]: columns j < NJ suffice (a few SGPRs per j step)
                 const EXA_AS4 double* DTm = ops_here<N>(ops_raw)->DT;
-                const int c = bt / NN, r = bt - c * NN;
-                const int l = r / NF, t = r - l * NF;
+                const int c = it > 0 ? bt / NN : k0 / NF;
+                const int r = it > 0 ? bt - c * NN : k0 - c * NF;
+                const int l = it > 0 ? r / NF : 0, t = it > 0 ? r - l * NF : r;
+                if constexpr (D == 0) did_x = true;
                 const int off = c * CS + l * SL + G::pbase(D, t);
 #pragma unroll
                 for (int i = 0; i < N; i++)
@@ -249,7 +260,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         __syncthreads();
         EXA_STAMP(2);
         {
-            if (grp == 0 && bt < TD) {                           // every read of Q is done: Q := S_x
+            if (did_x) {                                             // every read of Q is done: Q := S_x
                 constexpr int ps = G::pstride(0);
 #pragma unroll
                 for (int i = 0; i < N; i++)
@@ -261,7 +272,20 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             EXA_STAMP(11);
         }
         // ---- time contraction, split by variable between the two lanes of a pair
-        if (t_task) {
+        if (t_task && it == 0) {
+            const EXA_AS4 double* Ts = ops_here<N>(ops_raw)->Tsum;        // row sums of T
+#pragma unroll
+            for (int vv = 0; vv < NVA; vv++) {
+                if (v0 + vv < v1) {
+                    const int o = toff + ((v0 + vv) * NTS + 0) * SL;
+                    double x = EXA_LD(o) + EXA_LD(o + ASZ);
+                    if constexpr (DIM == 3) x += EXA_LD(o + 2 * ASZ);
+                    const double uv = tg ? ur[(NVA + vv) < NV ? NVA + vv : NV - 1] : ur[vv];
+#pragma unroll
+                    for (int lp = 0; lp < N; lp++) EXA_ST(toff + ((v0 + vv) * NTS + lp) * SL, uv - dt * Ts[lp] * x);
+                }
+            }
+        } else if (t_task) {
             const EXA_AS4 double* Tm = ops_here<N>(ops_raw)->T;
             double S[NVA][N];
 #pragma unroll

@@ -15,7 +15,7 @@ int main() {
     hipMalloc(&u, ndof * 8); hipMalloc(&tr, ntr * 8); hipMalloc(&ops, sizeof(DgOps<N>));
     hipMemcpy(u, h.data(), ndof * 8, hipMemcpyHostToDevice);
     DgOps<N> o{};   // the values do not matter for timing shares; keep them finite and small
-    for (int i = 0; i < N; i++) { o.w[i] = 1.0 / N; o.iw[i] = N; o.phiL[i] = 0.1; o.phiR[i] = 0.1; for (int j = 0; j < N; j++) { o.D[i*N+j] = 0.01*(i-j); o.DT[j*N+i] = 0.01*(i-j); o.Kxi[i*N+j] = 0.01; o.T[i*N+j] = 0.01; } }
+    for (int i = 0; i < N; i++) { o.w[i] = 1.0 / N; o.iw[i] = N; o.phiL[i] = 0.1; o.phiR[i] = 0.1; o.Tsum[i] = 0.06; for (int j = 0; j < N; j++) { o.D[i*N+j] = 0.01*(i-j); o.DT[j*N+i] = 0.01*(i-j); o.Kxi[i*N+j] = 0.01; o.T[i*N+j] = 0.01; } }
     hipMemcpy(ops, &o, sizeof(o), hipMemcpyHostToDevice);
     auto kern = dg_stage_a_kernel<DIM, N, Euler, CPB>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SA::LDS_BYTES);
