@@ -170,7 +170,7 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
     const DgLaunchTable* tab = dg_launch_table(dim, pde);
     if (!tab) { set_error("ADER-DG: no kernels for dim %d, pde %d", dim, pde); return EXA_ERR_INVALID; }
     if (N < 2 || N > tab->max_n) {
-        set_error("ADER-DG: N = %d unsupported for dim %d (2..%d; larger cells exceed the 160 KiB LDS image)", N, dim, tab->max_n);
+        set_error("ADER-DG: N = %d unsupported for dim %d (2..%d)", N, dim, tab->max_n);
         return EXA_ERR_INVALID;
     }
     if (n_vars != tab->nv) { set_error("ADER-DG: pde %d evolves %d variables, got n_vars = %d", pde, tab->nv, n_vars); return EXA_ERR_INVALID; }
@@ -202,12 +202,24 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
         set_error("operator block upload failed: %s", hipGetErrorString(e));
         return EXA_ERR_HIP;
     }
+    p->ops.scratch = nullptr;
+    const size_t sb = tab->scratch_bytes(N);
+    if (sb > 0) {
+        e = hipMalloc(&p->ops.scratch, sb);
+        if (e != hipSuccess) {
+            (void)hipFree(p->ops.dev);
+            delete p;
+            set_error("scratch slab (%zu B) allocation failed: %s", sb, hipGetErrorString(e));
+            return EXA_ERR_ALLOC;
+        }
+    }
     *plan = p;
     return EXA_OK;
 }
 
 int exa_dg_plan_destroy(exa_dg_plan* plan) {
     if (plan) {
+        if (plan->ops.scratch) (void)hipFree(plan->ops.scratch);
         if (plan->ops.dev) (void)hipFree(plan->ops.dev);
         delete plan;
     }

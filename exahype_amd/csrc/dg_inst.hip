@@ -20,8 +20,9 @@ using PDE = Advection<1>;
 #endif
 
 constexpr int DIM = EXA_DIM;
+constexpr int SCRATCH_BLOCKS = 256;            // persistent grid of the scratch variant: one workgroup per CU
 #if EXA_DIM == 3
-constexpr int MAX_N = 6;                       // N = 7, 8 need > 160 KiB of LDS per cell
+constexpr int MAX_N = 8;                       // N = 7, 8: cell image > 160 KiB of LDS -> scratch variant (functional fallback)
 constexpr int NT_A = 256;                      // base threads (tasks per phase ~ CPB * N^3 <= 256)
 __host__ __device__ constexpr int cpb_of(int N) { return N == 2 ? 16 : N == 3 ? 8 : N == 4 ? 4 : N == 5 ? 2 : 1; }
 #ifndef EXA_HS
@@ -57,12 +58,22 @@ template <int N> static DgOps<N> pack_ops(const DgOpsHost* h) {
 // device image of the operator block for this N (uploaded once per plan by capi.cpp)
 template <int N> static void fill_ops(const DgOpsHost* h, void* dst) { *static_cast<DgOps<N>*>(dst) = pack_ops<N>(h); }
 
+template <int N> constexpr bool needs_scratch() { return StageA<DIM, N, PDE, cpb_of(N)>::LDS_BYTES > 160 * 1024; }
+
 template <int N>
 static int launch_a(const double* u_in, double* u_out, double* trace, long ncells, const CellBox* box, double dt,
                     const double* idx, int n_it, const DgOpsHost* ops, hipStream_t s) {
     constexpr int CPB = cpb_of(N);
+    if (box->nbox <= 0) return 0;
+    if constexpr (needs_scratch<N>()) {
+        if (!ops->scratch) { set_error("stage_a: scratch slab missing for N = %d", N); return -1; }
+        hipLaunchKernelGGL((dg_stage_a_scratch_kernel<DIM, N, PDE, 1, 256>), dim3(SCRATCH_BLOCKS), dim3(256), 0, s, u_in, u_out,
+                           trace, ncells, *box, dt, idx[0], idx[1], idx[2], n_it, pack_ops<N>(ops), static_cast<double*>(ops->scratch));
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) { set_error("stage_a (scratch) launch (dim %d, N %d): %s", DIM, N, hipGetErrorString(e0)); return -2; }
+        return 0;
+    } else {
     using SA = StageA<DIM, N, PDE, CPB>;
-    static_assert(SA::LDS_BYTES <= 160 * 1024, "cell image exceeds the 160 KiB LDS of a gfx950 CU");
     auto kern = dg_stage_a_kernel<DIM, N, PDE, CPB>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -74,7 +85,6 @@ static int launch_a(const double* u_in, double* u_out, double* trace, long ncell
         }
         attr_set = true;
     }
-    if (box->nbox <= 0) return 0;
     if (n_it == 0) {            // single-stage variant: lean LDS image, many cells per workgroup
         constexpr int NT1 = 256;
         constexpr int NNc = ipow(N, DIM);
@@ -98,6 +108,12 @@ static int launch_a(const double* u_in, double* u_out, double* trace, long ncell
         return -2;
     }
     return 0;
+    }
+}
+
+template <int N> static size_t scratch_bytes_n() {
+    if constexpr (needs_scratch<N>()) return (size_t)SCRATCH_BLOCKS * StageAScratch<DIM, N, PDE, 1>::LDS_BYTES;
+    else return 0;
 }
 
 template <int N>
@@ -136,11 +152,7 @@ static int launch_b(double* u, const double* trace, const StageBBox* box, long n
 }
 
 #define EXA_N_CASES(X) X(2) X(3) X(4) X(5) X(6)
-#if EXA_DIM == 2
 #define EXA_N_CASES_HI(X) X(7) X(8)
-#else
-#define EXA_N_CASES_HI(X)
-#endif
 
 static int stage_a(int N, const double* u_in, double* u_out, double* trace, long ncells, const CellBox* box, double dt,
                    const double* idx, int n_it, const DgOpsHost* ops, hipStream_t s) {
@@ -176,6 +188,16 @@ static size_t ops_image(int N, const DgOpsHost* h, void* dst) {
     return 0;
 }
 
+static size_t scratch_bytes(int N) {
+    switch (N) {
+#define X(n) case n: return scratch_bytes_n<n>();
+        EXA_N_CASES(X)
+        EXA_N_CASES_HI(X)
+#undef X
+    }
+    return 0;
+}
+
 static int maxeig(const double* u, long nnodes, double* out, hipStream_t s) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(double), s);
     if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return -2; }
@@ -198,6 +220,7 @@ const DgLaunchTable* EXA_CAT(dg_table_, EXA_DIM, EXA_PDE_ID)() {
     t.stage_b = stage_b;
     t.maxeig = maxeig;
     t.ops_image = ops_image;
+    t.scratch_bytes = scratch_bytes;
     return &t;
 }
 

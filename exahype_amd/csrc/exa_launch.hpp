@@ -12,6 +12,7 @@ struct DgOpsHost {
     double xi[MAXN], w[MAXN], D[MAXN * MAXN], Kxi[MAXN * MAXN], phiL[MAXN], phiR[MAXN], iK1[MAXN * MAXN],
         K1[MAXN * MAXN];
     void* dev;     // DgOps<N> image in HBM (read by the kernels through the constant address space)
+    void* scratch; // per-workgroup cell-image slabs of the scratch variant (N whose image exceeds LDS), else null
 };
 // dg_operators_host.cpp: Gauss-Legendre nodes by Newton, barycentric derivative
 // matrix, K1 inverse by Gauss-Jordan, all in long double.
@@ -31,6 +32,7 @@ struct DgLaunchTable {
                    const double* idx, const DgOpsHost* ops, hipStream_t s);
     int (*maxeig)(const double* u, long nnodes, double* out, hipStream_t s);
     size_t (*ops_image)(int N, const DgOpsHost* h, void* dst);   // dst == nullptr: size only
+    size_t (*scratch_bytes)(int N);                               // 0: the LDS kernel serves this N
 };
 // returns nullptr when (dim, pde) is not built
 const DgLaunchTable* dg_launch_table(int dim, int pde);

@@ -125,7 +125,8 @@ def test_fv_rejects_bad_config(exa):
 
 
 # ---- ADER-DG -----------------------------------------------------------------------------------
-DG_CASES = [(2, 4, (5, 3)), (2, 2, (4, 4)), (2, 8, (2, 3)), (3, 3, (3, 2, 2)), (3, 4, (2, 2, 3)), (3, 5, (2, 1, 3)), (3, 6, (2, 2, 2))]
+DG_CASES = [(2, 4, (5, 3)), (2, 2, (4, 4)), (2, 8, (2, 3)), (3, 3, (3, 2, 2)), (3, 4, (2, 2, 3)), (3, 5, (2, 1, 3)), (3, 6, (2, 2, 2)),
+            (3, 7, (2, 1, 2)), (3, 8, (1, 2, 2))]       # N = 7, 8 in 3-D (cfg 4's p = 7): scratch-variant stage A
 
 
 def _ops(N):
@@ -218,7 +219,7 @@ def test_dg_max_eigenvalue(exa, orc):
 def test_dg_rejects_unsupported(exa):
     from exahype_amd._lib import ExaHypeHipError
     with pytest.raises(ExaHypeHipError):
-        exa.AderDgSolver(3, 8, (2, 2, 2))          # p = 7 in 3-D: LDS image does not fit
+        exa.AderDgSolver(3, 9, (2, 2, 2))          # N > 8 is not built
     with pytest.raises(ExaHypeHipError):
         exa.AderDgSolver(3, 4, (2, 2, 2), n_vars=4)
 
