@@ -131,7 +131,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     constexpr int NV = PDE::NV, NA = PDE::NAUX;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL, NTS = G::NTS;
     constexpr int ASZ = SA::ASZ, CS = SA::CS;
-    constexpr int NVA = (NV + 1) / 2;                        // variables of the first lane of a T pair
     constexpr int NJ = (N + 1) / 2;                          // columns of D kept (centro-antisymmetry)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ long cell_id[CPB];
@@ -144,13 +143,13 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     const double idx[3] = {idx0, idx1, idx2};
     if (tid < CPB) cell_id[tid] = box.cell(b0 + tid);
 
-    // ---- T-pair role of this thread: node x = tid / 2, variables [v0, v1)
-    // (the two lanes of a pair sit 32 lanes apart: every 16/32-lane LDS group then sees consecutive nodes)
-    const int tx = ((tid >> 6) << 5) | (tid & 31), tg = (tid >> 5) & 1;
-    const bool t_task = tx < TD;
-    const int tc = tx / NN, tn = tx - tc * NN;
+    // ---- time-update role of this thread: node bt, the variables [v0, v1) of its direction group
+    // (the update is split by variable over the DIM groups, so all waves take part in it)
+    constexpr int NVA = (NV + DIM - 1) / DIM;                // variables per group
+    const bool t_task = bt < TD;
+    const int tc = bt / NN, tn = bt - tc * NN;
     const int toff = tc * CS + G::node_off(tn);
-    const int v0 = tg ? NVA : 0, v1 = tg ? NV : NVA;
+    const int v0 = grp * NVA < NV ? grp * NVA : NV, v1 = (grp + 1) * NVA < NV ? (grp + 1) * NVA : NV;
 
     __syncthreads();                                             // cell_id visible
     // ---- load u (both lanes of a pair read the node: 40 contiguous bytes), q_l := u for every l
@@ -158,7 +157,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     {
         const long cell = t_task ? cell_id[tc] : -1;
 #pragma unroll
-        for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + tn) * NV + v] : 1.0;
+        for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + tn) * NV + v] : 1.0;   // (every group reads the node: L1-resident)
         if (t_task && n_it > 0) {
 #pragma unroll
             for (int l = 0; l < N; l++)
@@ -166,6 +165,15 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 for (int v = 0; v < NV; v++)
                     if (v >= v0 && v < v1) lds[toff + (v * NTS + l) * SL] = ur[v];
         }
+    }
+    double ur_mine[NVA];                                         // u of my variables (static register indices)
+#pragma unroll
+    for (int vv = 0; vv < NVA; vv++) {
+        double x = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++)
+            if (v == v0 + vv) x = ur[v];
+        ur_mine[vv] = x;
     }
     __syncthreads();
     EXA_STAMP(0);
@@ -280,34 +288,41 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                     const int o = toff + ((v0 + vv) * NTS + 0) * SL;
                     double x = EXA_LD(o) + EXA_LD(o + ASZ);
                     if constexpr (DIM == 3) x += EXA_LD(o + 2 * ASZ);
-                    const double uv = tg ? ur[(NVA + vv) < NV ? NVA + vv : NV - 1] : ur[vv];
+                    const double uv = ur_mine[vv];
 #pragma unroll
                     for (int lp = 0; lp < N; lp++) EXA_ST(toff + ((v0 + vv) * NTS + lp) * SL, uv - dt * Ts[lp] * x);
                 }
             }
         } else if (t_task) {
             const EXA_AS4 double* Tm = ops_here<N>(ops_raw)->T;
-            double S[NVA][N];
-#pragma unroll
-            for (int vv = 0; vv < NVA; vv++)
+            // software pipeline over the variables: the loads of variable vv+1 are in flight while the
+            // FMAs of variable vv run (all-loads-then-all-FMAs cost LDS time + VALU time back to back)
+            double Sa[N], Sb[N], Sc[N];
+            auto issue = [&](int vv) {
 #pragma unroll
                 for (int l = 0; l < N; l++) {
                     const int o = toff + ((v0 + vv) * NTS + l) * SL;
-                    double x = 0.0;
-                    if (v0 + vv < v1) {
-                        x = EXA_LD(o) + EXA_LD(o + ASZ);
-                        if constexpr (DIM == 3) x += EXA_LD(o + 2 * ASZ);
-                    }
-                    S[vv][l] = x;
+                    Sa[l] = (v0 + vv < v1) ? EXA_LD(o) : 0.0;
+                    Sb[l] = (v0 + vv < v1) ? EXA_LD(o + ASZ) : 0.0;
+                    if constexpr (DIM == 3) Sc[l] = (v0 + vv < v1) ? EXA_LD(o + 2 * ASZ) : 0.0;
                 }
+            };
+            issue(0);
 #pragma unroll
             for (int vv = 0; vv < NVA; vv++) {
-                const double uv = tg ? ur[(NVA + vv) < NV ? NVA + vv : NV - 1] : ur[vv];
+                double S[N];
+#pragma unroll
+                for (int l = 0; l < N; l++) {
+                    S[l] = Sa[l] + Sb[l];
+                    if constexpr (DIM == 3) S[l] += Sc[l];
+                }
+                if (vv + 1 < NVA) issue(vv + 1);
+                const double uv = ur_mine[vv];
 #pragma unroll
                 for (int lp = 0; lp < N; lp++) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int l = 0; l < N; l++) EXA_FMA(acc, Tm[lp * N + l], S[vv][l]);
+                    for (int l = 0; l < N; l++) EXA_FMA(acc, Tm[lp * N + l], S[l]);
                     if (v0 + vv < v1) EXA_ST(toff + ((v0 + vv) * NTS + lp) * SL, uv - dt * acc);
                 }
             }

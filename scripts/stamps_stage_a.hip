@@ -26,7 +26,7 @@ int main() {
         hipLaunchKernelGGL(kern, dim3(ncells), dim3(SA::NT), SA::LDS_BYTES, 0, u, u, tr, ncells, box, 1e-5, nc * 1.0, nc * 1.0, nc * 1.0, N, ops);
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(z, HIP_SYMBOL(g_exa_stamps), sizeof(z));
-        const char* names[12] = {"load+init", "D work", "D barrier", "T work", "T barrier", "aux work", "aux barrier", "avg (F1)", "vol+traces (F2)", "store (F3)", "z store", "z barrier"};
+        const char* names[12] = {"load+init", "D work", "D barrier", "T work", "T barrier", "T: loads done", "-", "avg (F1)", "vol+traces (F2)", "store (F3)", "z store", "z barrier"};
         if (rep == 0) continue;
         printf("cycles per cell, first wave of each direction group (x, y, z):\n");
         for (int k = 0; k < 12; k++) printf("   %-18s %9.0f %9.0f %9.0f\n", names[k], (double)z[k] / ncells, (double)z[12 + k] / ncells, (double)z[24 + k] / ncells);
