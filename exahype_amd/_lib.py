@@ -18,6 +18,7 @@ SIGNATURES = {
     "exa_version": (C.c_int, []),
     "exa_last_error": (C.c_char_p, []),
     "exa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "exa_register_pde": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "exa_pde_eval_device": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _vp, _vp, _vp, _vp]),
     "exa_fv_plan_create": (C.c_int, [C.c_int] * 7 + [C.c_long, C.c_int, C.POINTER(_vp)]),
     "exa_fv_plan_destroy": (C.c_int, [_vp]),
@@ -86,6 +87,13 @@ def device_count():
     n = C.c_int(0)
     rc = load().exa_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def register_pde(library_path):
+    """Register a user PDE side library (exahype_amd/pde_codegen.py); returns its pde id (>= 100)."""
+    pid = C.c_int(-1)
+    check(load().exa_register_pde(library_path.encode(), C.byref(pid)))
+    return pid.value
 
 
 def darr(vals):

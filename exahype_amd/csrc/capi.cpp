@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <dlfcn.h>
 #include "../../include/exahype_hip.h"
 #include "exa_launch.hpp"
 
@@ -33,7 +34,28 @@ void set_error(const char* fmt, ...) {
 
 const DgLaunchTable *dg_table_2_0(), *dg_table_2_1(), *dg_table_2_2(), *dg_table_3_1(), *dg_table_3_2();
 
+// ---- run-time registered PDE term sets (side libraries generated from SymPy expressions) -------------
+struct UserPde {
+    void* handle;
+    const DgLaunchTable* dg[4];
+    int nv;
+    int (*fv)(int, int, int, int, int, int, long, double*, double, double, void*);
+    int (*ev)(int, long, int, const double*, double*, double*, void*);
+};
+static std::vector<UserPde> g_user;
+
+int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
+                   double h, hipStream_t s) {
+    if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].fv) { set_error("pde %d is not registered", pde); return -1; }
+    return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, (void*)s);
+}
+int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s) {
+    if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].ev) { set_error("pde %d is not registered", pde); return -1; }
+    return g_user[pde - 100].ev(normal, n, stride, Q, F, lam, (void*)s);
+}
+
 const DgLaunchTable* dg_launch_table(int dim, int pde) {
+    if (pde >= 100) return (pde - 100 < (int)g_user.size() && dim >= 2 && dim <= 3) ? g_user[pde - 100].dg[dim] : nullptr;
     if (dim == 2 && pde == 0) return dg_table_2_0();
     if (dim == 2 && pde == 1) return dg_table_2_1();
     if (dim == 2 && pde == 2) return dg_table_2_2();
@@ -87,8 +109,35 @@ static int use_device(int device) {
     return EXA_OK;
 }
 
+int exa_register_pde(const char* library_path, int* pde_id) {
+    if (!library_path || !pde_id) { set_error("exa_register_pde: NULL argument"); return EXA_ERR_INVALID; }
+    void* h = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { set_error("exa_register_pde: %s", dlerror()); return EXA_ERR_INVALID; }
+    UserPde u{};
+    u.handle = h;
+    typedef const void* (*tab_fn)();
+    for (int d = 2; d <= 3; d++) {
+        char name[64];
+        snprintf(name, sizeof(name), "exa_user_dg_table_%d", d);
+        tab_fn f = (tab_fn)dlsym(h, name);
+        u.dg[d] = f ? static_cast<const DgLaunchTable*>(f()) : nullptr;
+    }
+    int (*nvf)() = (int (*)())dlsym(h, "exa_user_nv");
+    u.fv = (decltype(u.fv))dlsym(h, "exa_user_fv_launch");
+    u.ev = (decltype(u.ev))dlsym(h, "exa_user_pde_eval");
+    if (!nvf || (!u.dg[2] && !u.dg[3] && !u.fv)) { dlclose(h); set_error("%s exports no exahype_amd PDE entry points", library_path); return EXA_ERR_INVALID; }
+    u.nv = nvf();
+    g_user.push_back(u);
+    *pde_id = 100 + (int)g_user.size() - 1;
+    return EXA_OK;
+}
+
 int exa_pde_eval_device(int pde, int normal, long n, int stride, const double* Q_dev, double* F_dev, double* lambda_dev,
                         void* stream) {
+    if (pde >= 100) {
+        if (normal < 0 || normal > 2 || n < 0 || stride < 1 || !Q_dev) { set_error("exa_pde_eval_device: bad argument"); return EXA_ERR_INVALID; }
+        return pde_eval_launch(pde, normal, n, stride, Q_dev, F_dev, lambda_dev, (hipStream_t)stream);
+    }
     if (pde < 0 || pde > 2 || normal < 0 || normal > 2 || n < 0 || stride < 1 || !Q_dev) {
         set_error("exa_pde_eval_device: bad argument");
         return EXA_ERR_INVALID;
@@ -112,7 +161,10 @@ int exa_fv_plan_create(int device, int mode, int dim, int patch_size, int halo_s
     if (n_real < 1 || n_real > 8 || n_aux < 0 || n_patches < 0) { set_error("n_real must be 1..8, n_aux >= 0, n_patches >= 0"); return EXA_ERR_INVALID; }
     if (pde == EXA_PDE_EULER_REF2D && (dim != 2 || n_real < 4)) { set_error("EULER_REF2D is the reference's 2-D term set (n_real >= 4)"); return EXA_ERR_INVALID; }
     if (pde == EXA_PDE_EULER && n_real < 5) { set_error("EULER needs n_real >= 5"); return EXA_ERR_INVALID; }
-    if (pde < 0 || pde > 2) { set_error("unknown pde %d", pde); return EXA_ERR_INVALID; }
+    if (pde >= 100) {
+        if (pde - 100 >= (int)g_user.size()) { set_error("pde %d is not registered", pde); return EXA_ERR_INVALID; }
+        if (n_real < g_user[pde - 100].nv) { set_error("pde %d evolves %d variables; n_real = %d", pde, g_user[pde - 100].nv, n_real); return EXA_ERR_INVALID; }
+    } else if (pde < 0 || pde > 2) { set_error("unknown pde %d", pde); return EXA_ERR_INVALID; }
     const long ncell = lpow(patch_size, dim);
     if (ncell > 4096) { set_error("FV patch with %ld volumes exceeds the 4096 a workgroup keeps in registers", ncell); return EXA_ERR_INVALID; }
     int rc = use_device(device);

@@ -42,6 +42,11 @@ int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_pat
               double h, hipStream_t s);
 int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
 
+// user PDE term sets registered at run time (capi.cpp: exa_register_pde), pde ids >= 100
+int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
+                   double h, hipStream_t s);
+int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
+
 void set_error(const char* fmt, ...);
 
 }  // namespace exa

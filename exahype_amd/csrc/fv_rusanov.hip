@@ -19,6 +19,9 @@
 #include <cstdio>
 #include "exa_launch.hpp"
 #include "exa_pde.hpp"
+#ifdef EXA_USER_PDE_HEADER
+#include EXA_USER_PDE_HEADER      // struct exa::UserPDE (exahype_amd/pde_codegen.py)
+#endif
 
 namespace exa {
 
@@ -250,11 +253,37 @@ static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double*
     return fv_dispatch<DIM, PDE, 1>(P, H, m, V, n_patches, Q, dt, h, s);
 }
 
+#ifdef EXA_USER_PDE_HEADER
+}  // namespace exa
+// user-PDE side library: the same fused kernel instantiated for exa::UserPDE
+extern "C" int exa_user_nv() { return exa::UserPDE::NV; }
+extern "C" int exa_user_fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
+                                  double h, void* stream) {
+    using namespace exa;
+    const int V = n_real + n_aux;
+    if (n_real > MAXV || n_real < UserPDE::NV) { set_error("user PDE evolves %d variables; n_real = %d", UserPDE::NV, n_real); return -1; }
+    if (n_patches <= 0) return 0;
+    if (dim == 2) return fv_mode<2, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, (hipStream_t)stream);
+    if (dim == 3 && UserPDE::MAXDIM >= 3) return fv_mode<3, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, (hipStream_t)stream);
+    set_error("user PDE: no FV kernel for dim %d", dim);
+    return -1;
+}
+extern "C" int exa_user_pde_eval(int normal, long n, int stride, const double* Q, double* F, double* lam, void* stream) {
+    using namespace exa;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((pde_eval_kernel<UserPDE>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, normal, n, stride, Q, F, lam);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("pde_eval launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+namespace exa {
+#else
 int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
               double h, hipStream_t s) {
     const int V = n_real + n_aux;
     if (n_real > MAXV) { set_error("n_real = %d exceeds %d", n_real, MAXV); return -1; }
     if (n_patches <= 0) return 0;
+    if (pde >= 100) return user_fv_launch(pde, mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, s);
     if (dim == 2) {
         if (pde == 0) return fv_mode<2, EulerRef2D>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
         if (pde == 1) return fv_mode<2, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
@@ -269,6 +298,7 @@ int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_pat
 
 int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s) {
     if (n <= 0) return 0;
+    if (pde >= 100) return user_pde_eval(pde, normal, n, stride, Q, F, lam, s);
     const dim3 grid((unsigned)((n + 255) / 256));
     if (pde == 0) hipLaunchKernelGGL((pde_eval_kernel<EulerRef2D>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
     else if (pde == 1) hipLaunchKernelGGL((pde_eval_kernel<Euler>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
@@ -278,5 +308,7 @@ int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, do
     if (e != hipSuccess) { set_error("pde_eval launch: %s", hipGetErrorString(e)); return -2; }
     return 0;
 }
+
+#endif
 
 }  // namespace exa

@@ -98,9 +98,14 @@ class HIPPrinter(CodePrinter):
         self.scheme = scheme
         if pde is None:
             pde = "euler_ref2d" if (scheme != "aderdg" and k.dim == 2) else "euler"
-        if pde not in PDE_IDS:
-            raise ValueError("unknown PDE term set %r (have %s)" % (pde, sorted(PDE_IDS)))
-        self.pde = PDE_IDS[pde]
+        self.user_pde = None
+        if hasattr(pde, "register") and hasattr(pde, "source"):      # a SympyPDE: compiled for the device on compile()
+            self.user_pde = pde
+            self.pde = -1
+        elif pde not in PDE_IDS:
+            raise ValueError("unknown PDE term set %r (have %s, or a pde_codegen.SympyPDE)" % (pde, sorted(PDE_IDS)))
+        else:
+            self.pde = PDE_IDS[pde]
         self.n_picard = n_picard
         if scheme == "aderdg":
             if k.halo_size != 0 or k.n_aux != 0:
@@ -142,7 +147,8 @@ class HIPPrinter(CodePrinter):
         V = k.n_real + k.n_aux
         L = ["// exahype_amd HIP dispatch plan for `%s` (MI355X / gfx950)" % self.functionName(),
              "// scheme     : %s" % self.scheme,
-             "// pde terms  : %s  <- %s" % (_PDE_DOC[self.pde], ", ".join(k.functions))]
+             "// pde terms  : %s  <- %s" % (_PDE_DOC.get(self.pde, "user term set from SymPy expressions (pde_codegen.SympyPDE, JIT-compiled)"),
+                                            ", ".join(k.functions))]
         if self.scheme == "aderdg":
             N = k.patch_size
             L += ["// kernels    : dg_stage_a_kernel<%d,%d> (predictor + volume + face traces), dg_stage_b_kernel<%d,%d> (Riemann + corrector)"
@@ -172,6 +178,8 @@ class HIPPrinter(CodePrinter):
         """Bind libexahype_hip.so (built with hipcc if missing) and create the plan.  Raises without a GPU."""
         from .. import solvers
         k = self.kernel()
+        if self.user_pde is not None and self.pde < 0:
+            self.pde = self.user_pde.register()
         if self._impl is None:
             if self.scheme == "aderdg":
                 self._impl = solvers.AderDgSolver(k.dim, k.patch_size, self.grid, pde=self.pde, n_vars=k.n_real,

@@ -64,6 +64,12 @@ int exa_version(void);
 const char* exa_last_error(void);
 int exa_device_count(int* count);
 
+/* ---- user PDE term sets ------------------------------------------------------- */
+/* The reference resolves `Flux` / `maxEigenvalue` at link time to user C++ (Unit test/Functions.h:2-3).
+ * Here a user term set is a side library generated from SymPy expressions and compiled with hipcc
+ * (exahype_amd/pde_codegen.py); registering it yields a pde id >= 100 usable wherever EXA_PDE_* is. */
+int exa_register_pde(const char* library_path, int* pde_id);
+
 /* ---- point-wise PDE terms (Functions.h:2-3) ---------------------------------- */
 /* For n states Q_dev[n][stride] and a normal: F_dev[n][stride] (first n_flux
  * entries written) and lambda_dev[n].  Either output may be NULL. */
