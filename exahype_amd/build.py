@@ -27,6 +27,7 @@ UNITS = [
     ("dg_operators_host.cpp", "dg_operators_host", ["-x", "hip"]),
     # bit-exact with the g++ build of the reference: no FMA contraction in the FV unit
     ("fv_rusanov.hip", "fv_rusanov", ["-ffp-contract=off"]),
+    ("limiter.hip", "limiter", []),
 ] + [
     ("dg_inst.hip", f"dg_{dim}_{pde}", [f"-DEXA_DIM={dim}", f"-DEXA_PDE_ID={pde}"])
     for dim, pde in ((3, 1), (2, 1), (2, 0), (3, 2), (2, 2))

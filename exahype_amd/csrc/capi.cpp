@@ -255,6 +255,7 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
         return EXA_ERR_HIP;
     }
     p->ops.scratch = nullptr;
+    p->ops.lim = nullptr;
     const size_t sb = tab->scratch_bytes(N);
     if (sb > 0) {
         e = hipMalloc(&p->ops.scratch, sb);
@@ -272,6 +273,7 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
 int exa_dg_plan_destroy(exa_dg_plan* plan) {
     if (plan) {
         if (plan->ops.scratch) (void)hipFree(plan->ops.scratch);
+        if (plan->ops.lim) (void)hipFree(plan->ops.lim);
         if (plan->ops.dev) (void)hipFree(plan->ops.dev);
         delete plan;
     }
@@ -384,6 +386,47 @@ int exa_dg_pack_face(exa_dg_plan* p, const double* trace_dev, int d, int side, d
     EXA_HIP(hipMemcpy2DAsync(buf_dev, (size_t)inner * TS * sizeof(double), src, (size_t)p->nc[d] * inner * TS * sizeof(double),
                              (size_t)inner * TS * sizeof(double), (size_t)outer, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return EXA_OK;
+}
+
+/* ---- FV subcell limiter glue ------------------------------------------------------ */
+
+int exa_lim_operators(const exa_dg_plan* p, double* P, double* R) {
+    if (!p || !P || !R) { set_error("exa_lim_operators: NULL argument"); return EXA_ERR_INVALID; }
+    if (build_limiter_operators(&p->ops, 2 * p->N - 1, P, R) != 0) { set_error("limiter operator construction failed"); return EXA_ERR_INVALID; }
+    return EXA_OK;
+}
+
+long exa_lim_patch_count(const exa_dg_plan* p) { return p ? lpow(2 * p->N + 1, p->dim) * p->nv : 0; }
+
+static int lim_tables(exa_dg_plan* p) {
+    if (p->ops.lim) return EXA_OK;
+    const int N = p->N, Ns = 2 * N - 1;
+    std::vector<double> t(2 * (size_t)N * Ns);
+    if (build_limiter_operators(&p->ops, Ns, t.data(), t.data() + (size_t)N * Ns) != 0) { set_error("limiter operator construction failed"); return EXA_ERR_INVALID; }
+    EXA_HIP(hipMalloc(&p->ops.lim, t.size() * sizeof(double)));
+    EXA_HIP(hipMemcpy(p->ops.lim, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return EXA_OK;
+}
+
+int exa_dg_project_patches(exa_dg_plan* p, const double* u_dev, const long* cells_dev, long n, double* patch_dev, void* stream) {
+    if (!p || !u_dev || (n > 0 && (!cells_dev || !patch_dev)) || n < 0) { set_error("exa_dg_project_patches: bad argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    rc = lim_tables(p);
+    if (rc) return rc;
+    const int Ns = 2 * p->N - 1;
+    return limiter_project(p->dim, p->N, Ns, p->nv, p->nc, u_dev, cells_dev, n, patch_dev, static_cast<const double*>(p->ops.lim), (hipStream_t)stream);
+}
+
+int exa_dg_reconstruct_patches(exa_dg_plan* p, const double* patch_dev, const long* cells_dev, long n, double* u_dev, void* stream) {
+    if (!p || !u_dev || (n > 0 && (!cells_dev || !patch_dev)) || n < 0) { set_error("exa_dg_reconstruct_patches: bad argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    rc = lim_tables(p);
+    if (rc) return rc;
+    const int Ns = 2 * p->N - 1;
+    return limiter_reconstruct(p->dim, p->N, Ns, p->nv, patch_dev, cells_dev, n, u_dev,
+                               static_cast<const double*>(p->ops.lim) + (size_t)p->N * Ns, (hipStream_t)stream);
 }
 
 int exa_dg_max_eigenvalue(exa_dg_plan* p, const double* u_dev, double* lambda_dev, void* stream) {

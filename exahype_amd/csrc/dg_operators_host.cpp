@@ -109,4 +109,61 @@ int build_dg_operators(int N, DgOpsHost* o) {
     return 0;
 }
 
+// FV subcell limiter: P[s][i] = Ns * int_{s/Ns}^{(s+1)/Ns} phi_i (Gauss-Legendre on every
+// subinterval: exact), R = argmin ||P u - v||^2 s.t. w.u = mean(v) (KKT system, Gauss-Jordan in long double).
+int build_limiter_operators(const DgOpsHost* o, int Ns, double* P, double* R) {
+    const int N = o->N;
+    if (Ns < 1 || Ns > 2 * MAXN) return -1;
+    ld Pm[2 * MAXN][MAXN];
+    for (int s = 0; s < Ns; s++)
+        for (int i = 0; i < N; i++) Pm[s][i] = 0.0L;
+    for (int s = 0; s < Ns; s++)
+        for (int k = 0; k < N; k++) {
+            const ld x = ((ld)s + (ld)o->xi[k]) / Ns;              // the GL nodes/weights of the element serve as the rule
+            for (int i = 0; i < N; i++) {
+                ld phi = 1.0L;
+                for (int m = 0; m < N; m++)
+                    if (m != i) phi *= (x - (ld)o->xi[m]) / ((ld)o->xi[i] - (ld)o->xi[m]);
+                Pm[s][i] += (ld)o->w[k] * phi;
+            }
+        }
+    for (int s = 0; s < Ns; s++)
+        for (int i = 0; i < N; i++) P[s * N + i] = (double)Pm[s][i];
+    // KKT: [2 P^T P, w; w^T, 0] [u; lambda] = [2 P^T v; mean(v)]
+    const int M = N + 1;
+    ld K[MAXN + 1][MAXN + 1 + 2 * MAXN];
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M + Ns; j++) K[i][j] = 0.0L;
+    for (int i = 0; i < N; i++) {
+        for (int j = 0; j < N; j++) {
+            ld a = 0.0L;
+            for (int s = 0; s < Ns; s++) a += Pm[s][i] * Pm[s][j];
+            K[i][j] = 2.0L * a;
+        }
+        K[i][N] = (ld)o->w[i];
+        K[N][i] = (ld)o->w[i];
+        for (int s = 0; s < Ns; s++) K[i][M + s] = 2.0L * Pm[s][i];
+    }
+    for (int s = 0; s < Ns; s++) K[N][M + s] = 1.0L / Ns;
+    for (int c = 0; c < M; c++) {
+        int piv = c;
+        for (int r = c + 1; r < M; r++)
+            if (fabsl(K[r][c]) > fabsl(K[piv][c])) piv = r;
+        if (K[piv][c] == 0.0L) return -1;
+        if (piv != c)
+            for (int k = 0; k < M + Ns; k++) { ld t = K[c][k]; K[c][k] = K[piv][k]; K[piv][k] = t; }
+        const ld inv = 1.0L / K[c][c];
+        for (int k = 0; k < M + Ns; k++) K[c][k] *= inv;
+        for (int r = 0; r < M; r++) {
+            if (r == c) continue;
+            const ld f = K[r][c];
+            if (f == 0.0L) continue;
+            for (int k = 0; k < M + Ns; k++) K[r][k] -= f * K[c][k];
+        }
+    }
+    for (int i = 0; i < N; i++)
+        for (int s = 0; s < Ns; s++) R[i * Ns + s] = (double)K[i][M + s];
+    return 0;
+}
+
 }  // namespace exa

@@ -12,11 +12,18 @@ struct DgOpsHost {
     double xi[MAXN], w[MAXN], D[MAXN * MAXN], Kxi[MAXN * MAXN], phiL[MAXN], phiR[MAXN], iK1[MAXN * MAXN],
         K1[MAXN * MAXN];
     void* dev;     // DgOps<N> image in HBM (read by the kernels through the constant address space)
+    void* lim;     // limiter tables in HBM: P[Ns][N] then R[N][Ns] (null until first use)
     void* scratch; // per-workgroup cell-image slabs of the scratch variant (N whose image exceeds LDS), else null
 };
 // dg_operators_host.cpp: Gauss-Legendre nodes by Newton, barycentric derivative
 // matrix, K1 inverse by Gauss-Jordan, all in long double.
 int build_dg_operators(int N, DgOpsHost* out);
+int build_limiter_operators(const DgOpsHost* o, int Ns, double* P, double* R);     // P[Ns][N], R[N][Ns]
+// limiter.hip
+int limiter_project(int dim, int N, int Ns, int nv, const long* nc, const double* u, const long* cells, long n, double* patch,
+                    const double* Pdev, hipStream_t s);
+int limiter_reconstruct(int dim, int N, int Ns, int nv, const double* patch, const long* cells, long n, double* u,
+                        const double* Rdev, hipStream_t s);
 
 struct StageBBox {
     long nc[3], lo[3], nb[3];

@@ -1,0 +1,158 @@
+// FV subcell limiter glue for the ADER-DG path (BASELINE configs[4]; no counterpart in the
+// reference).  Two small kernels around the fused FV Rusanov patch kernel (fv_rusanov.hip, the reference's kernel
+// shape with patch_size = 2p+1, halo_size = 1):
+//   limiter_project_kernel      troubled cell -> FV patch: interior = (P x P x P) u, face halos = the adjacent
+//                               subcell layer of the face neighbours' projections (periodic in the block), edge
+//                               and corner halo entries = nearest interior value (never read by the 7-point stencil)
+//   limiter_reconstruct_kernel  FV patch interior -> DG nodes: u = (R x R x R) v
+// One workgroup per troubled cell; the tensor products run variable by variable through two LDS buffers.  These
+// touch ~5 % of the cells: written for clarity, not tuned.
+#include <cstdio>
+#include "exa_launch.hpp"
+
+namespace exa {
+
+constexpr int LIM_MAX = 15 * 15 * 15;      // largest intermediate: Ns^3 at p = 7
+
+// out[.., r, ..] = sum_c M[r0 + r][c] in[.., c, ..] along `axis` of a row-major array with extents e[0..dim)
+// (extent C along `axis` on input, nr on output)
+__device__ inline void lim_apply(const double* __restrict__ M, int ldm, int r0, int nr, int C, const double* in, double* out,
+                                 int dim, const int* e, int axis) {
+    int inner = 1, outer = 1;
+    for (int a = axis + 1; a < dim; a++) inner *= e[a];
+    for (int a = 0; a < axis; a++) outer *= e[a];
+    const int total = outer * nr * inner;
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+        const int in_i = t % inner, r = (t / inner) % nr, o = t / (inner * nr);
+        double acc = 0.0;
+        for (int c = 0; c < C; c++) acc += M[(r0 + r) * ldm + c] * in[(o * C + c) * inner + in_i];
+        out[t] = acc;
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, const double* __restrict__ u,
+                       const long* __restrict__ cells, double* __restrict__ patch, const double* __restrict__ P) {
+    __shared__ double A[LIM_MAX], B[LIM_MAX];
+    const long cell = cells[blockIdx.x];
+    const int S = Ns + 2;
+    long NN = 1, SS = 1, NsD = 1;
+    for (int a = 0; a < DIM; a++) { NN *= N; SS *= S; NsD *= Ns; }
+    double* pt = patch + (long)blockIdx.x * SS * nv;
+    const long nc[3] = {nc0, nc1, nc2};
+    long cc[3];
+    { long b = cell; cc[2] = DIM == 3 ? b % nc2 : 0; if (DIM == 3) b /= nc2; cc[1] = b % nc1; cc[0] = b / nc1; }
+    for (int v = 0; v < nv; v++) {
+        // ---- own projection
+        for (int t = threadIdx.x; t < NN; t += blockDim.x) A[t] = u[(cell * NN + t) * nv + v];
+        __syncthreads();
+        int e[3] = {N, N, N};
+        double *src = A, *dst = B;
+        for (int a = 0; a < DIM; a++) {
+            lim_apply(P, N, 0, Ns, N, src, dst, DIM, e, a);
+            e[a] = Ns;
+            __syncthreads();
+            double* tmp = src; src = dst; dst = tmp;
+        }
+        // patch entry (I,J,K): nearest interior value; the face layers are overwritten below
+        for (int t = threadIdx.x; t < SS; t += blockDim.x) {
+            int I[3], r = t;
+            for (int a = DIM - 1; a >= 0; a--) { I[a] = r % S; r /= S; }
+            int flat = 0;
+            for (int a = 0; a < DIM; a++) {
+                int ci = I[a] - 1;
+                ci = ci < 0 ? 0 : (ci > Ns - 1 ? Ns - 1 : ci);
+                flat = flat * Ns + ci;
+            }
+            pt[(long)t * nv + v] = src[flat];
+        }
+        __syncthreads();
+        // ---- face halos from the neighbours' projections (one subcell layer each)
+        for (int a = 0; a < DIM; a++)
+            for (int side = 0; side < 2; side++) {
+                long nb[3] = {cc[0], cc[1], cc[2]};
+                nb[a] = (nb[a] + (side ? 1 : nc[a] - 1)) % nc[a];
+                const long ncell = (nb[0] * nc1 + nb[1]) * (DIM == 3 ? nc2 : 1) + nb[2];
+                for (int t = threadIdx.x; t < NN; t += blockDim.x) A[t] = u[(ncell * NN + t) * nv + v];
+                __syncthreads();
+                int e2[3] = {N, N, N};
+                double *s2 = A, *d2 = B;
+                for (int b = 0; b < DIM; b++) {
+                    if (b == a) lim_apply(P, N, side ? 0 : Ns - 1, 1, N, s2, d2, DIM, e2, b);     // the adjacent layer only
+                    else lim_apply(P, N, 0, Ns, N, s2, d2, DIM, e2, b);
+                    e2[b] = (b == a) ? 1 : Ns;
+                    __syncthreads();
+                    double* tmp = s2; s2 = d2; d2 = tmp;
+                }
+                long layer = NsD / Ns;
+                for (int t = threadIdx.x; t < layer; t += blockDim.x) {
+                    // t enumerates the transverse subcells (axes != a, lexicographic)
+                    int r = t, idx[3] = {0, 0, 0};
+                    for (int b = DIM - 1; b >= 0; b--) {
+                        if (b == a) continue;
+                        idx[b] = r % Ns + 1;
+                        r /= Ns;
+                    }
+                    idx[a] = side ? S - 1 : 0;
+                    long flat = 0;
+                    for (int b = 0; b < DIM; b++) flat = flat * S + idx[b];
+                    pt[flat * nv + v] = s2[t];
+                }
+                __syncthreads();
+            }
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+limiter_reconstruct_kernel(int N, int Ns, int nv, const double* __restrict__ patch, const long* __restrict__ cells,
+                           double* __restrict__ u, const double* __restrict__ R) {
+    __shared__ double A[LIM_MAX], B[LIM_MAX];
+    const long cell = cells[blockIdx.x];
+    const int S = Ns + 2;
+    long NN = 1, SS = 1, NsD = 1;
+    for (int a = 0; a < DIM; a++) { NN *= N; SS *= S; NsD *= Ns; }
+    const double* pt = patch + (long)blockIdx.x * SS * nv;
+    for (int v = 0; v < nv; v++) {
+        for (int t = threadIdx.x; t < NsD; t += blockDim.x) {
+            int r = t;
+            long flat = 0, mul = 1;
+            for (int a = DIM - 1; a >= 0; a--) { flat += (long)(r % Ns + 1) * mul; mul *= S; r /= Ns; }
+            A[t] = pt[flat * nv + v];
+        }
+        __syncthreads();
+        int e[3] = {Ns, Ns, Ns};
+        double *src = A, *dst = B;
+        for (int a = 0; a < DIM; a++) {
+            lim_apply(R, Ns, 0, N, Ns, src, dst, DIM, e, a);
+            e[a] = N;
+            __syncthreads();
+            double* tmp = src; src = dst; dst = tmp;
+        }
+        for (int t = threadIdx.x; t < NN; t += blockDim.x) u[(cell * NN + t) * nv + v] = src[t];
+        __syncthreads();
+    }
+}
+
+int limiter_project(int dim, int N, int Ns, int nv, const long* nc, const double* u, const long* cells, long n, double* patch,
+                    const double* Pdev, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (dim == 2) hipLaunchKernelGGL((limiter_project_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, cells, patch, Pdev);
+    else hipLaunchKernelGGL((limiter_project_kernel<3>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, cells, patch, Pdev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("limiter_project launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+int limiter_reconstruct(int dim, int N, int Ns, int nv, const double* patch, const long* cells, long n, double* u,
+                        const double* Rdev, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (dim == 2) hipLaunchKernelGGL((limiter_reconstruct_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, patch, cells, u, Rdev);
+    else hipLaunchKernelGGL((limiter_reconstruct_kernel<3>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, patch, cells, u, Rdev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("limiter_reconstruct launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+}  // namespace exa

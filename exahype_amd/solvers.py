@@ -412,3 +412,46 @@ def _dg_run(self, t_end, cfl=0.4, max_steps=1000000):
 
 
 AderDgSolver.run = _dg_run
+
+
+# ----------------------------------------------------------------------------------------------
+# FV subcell limiter (BASELINE configs[4])
+# ----------------------------------------------------------------------------------------------
+class SubcellLimiter:
+    """Limited ADER-DG step on one periodic block: untroubled cells take the DG step, troubled cells the FV
+    Rusanov patch update (patch_size 2p+1, halo 1 -- the reference's kernel shape) of their projected data.
+    The troubled mask is an input (synthetic Bernoulli mask in the benchmark; a physical detector is host logic
+    outside this path)."""
+
+    def __init__(self, solver):
+        if solver.halo is not None:
+            raise NotImplementedError("the limiter runs on a single periodic block this round (no subcell halo exchange yet)")
+        self.s = solver
+        self.Ns = 2 * solver.N - 1
+        self.patch_doubles = solver.lib.exa_lim_patch_count(solver._plan)
+        self._fv = {}
+
+    def operators(self):
+        N, Ns = self.s.N, self.Ns
+        P, R = np.zeros((Ns, N)), np.zeros((N, Ns))
+        check(self.s.lib.exa_lim_operators(self.s._plan, P.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p)))
+        return P, R
+
+    def step(self, dt, mask):
+        torch = _torch()
+        s = self.s
+        m = torch.as_tensor(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask)).to(s.dev).reshape(-1)
+        cells = torch.nonzero(m, as_tuple=False).reshape(-1).to(torch.int64).contiguous()
+        n = int(cells.numel())
+        patches = torch.empty((max(n, 1), self.patch_doubles), dtype=torch.float64, device=s.dev)
+        check(s.lib.exa_dg_project_patches(s._plan, C.c_void_p(s.u.data_ptr()), C.c_void_p(cells.data_ptr()), n,
+                                           C.c_void_p(patches.data_ptr()), _stream_ptr()))
+        s.step(dt)                                             # candidate DG solution everywhere
+        if n == 0:
+            return 0
+        if n not in self._fv:
+            self._fv[n] = FVRusanovKernel(s.dim, self.Ns, 1, s.nv, 0, n, pde=s.pde, mode=FV_RUSANOV, device=s.dev.index or 0)
+        self._fv[n].time_step(patches[:n].reshape(-1), dt, s.dx[0] / self.Ns)
+        check(s.lib.exa_dg_reconstruct_patches(s._plan, C.c_void_p(patches.data_ptr()), C.c_void_p(cells.data_ptr()), n,
+                                               C.c_void_p(s.u.data_ptr()), _stream_ptr()))
+        return n

@@ -133,6 +133,18 @@ int exa_dg_riemann_corrector(exa_dg_plan* plan, double* u_dev, const double* tra
  * to the low neighbour, which uses it as ghost_dev[d*2+1]); side 1 -> R traces
  * of the cells with c_d == ncells[d]-1 (-> the high neighbour's ghost_dev[d*2+0]). */
 int exa_dg_pack_face(exa_dg_plan* plan, const double* trace_dev, int d, int side, double* buf_dev, void* stream);
+/* FV subcell limiter glue (BASELINE configs[4]): N_s = 2N-1 subcells per axis.
+ * exa_lim_operators: host copies of the projection P[N_s][N] and the mean-preserving least-squares
+ * reconstruction R[N][N_s].  exa_dg_project_patches: for the n cells listed in cells_dev build FV patches
+ * patch_dev[n][(N_s+2)^dim][n_vars] (patch_size N_s, halo 1: interior = projected cell, face halos = adjacent
+ * subcell layer of the projected face neighbours, periodic in the block) ready for exa_fv_time_step_device;
+ * exa_dg_reconstruct_patches maps the patch interiors back onto the DG nodes of those cells. */
+int exa_lim_operators(const exa_dg_plan* plan, double* P, double* R);
+long exa_lim_patch_count(const exa_dg_plan* plan);
+int exa_dg_project_patches(exa_dg_plan* plan, const double* u_dev, const long* cells_dev, long n, double* patch_dev,
+                           void* stream);
+int exa_dg_reconstruct_patches(exa_dg_plan* plan, const double* patch_dev, const long* cells_dev, long n, double* u_dev,
+                               void* stream);
 /* max over all cells/nodes/directions of maxEigenvalue (for a CFL time step);
  * result is written to *lambda_dev (one double, device). */
 int exa_dg_max_eigenvalue(exa_dg_plan* plan, const double* u_dev, double* lambda_dev, void* stream);
