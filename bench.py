@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--cells", type=int, default=128, help="cells per axis per GPU (default: BASELINE configs[2])")
     ap.add_argument("--order", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path with host-staged exchange")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     a = ap.parse_args()
 
     import torch
@@ -100,11 +102,16 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     part = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
         part = exa.CartesianPartition(world, rank, 3)
     pdims = part.pdims if part else [1, 1, 1]
     coords = part.coords if part else [0, 0, 0]
@@ -112,7 +119,8 @@ def main():
     N = a.order + 1
     nc = [a.cells] * 3
     dx = [1.0 / (nc[d] * pdims[d]) for d in range(3)]
-    s = exa.AderDgSolver(3, N, nc, pde=exa.PDE_EULER, n_vars=5, n_picard=-1, dx=dx, device=local, part=part)
+    s = exa.AderDgSolver(3, N, nc, pde=exa.PDE_EULER, n_vars=5, n_picard=-1, dx=dx, device=local, part=part,
+                         backend_is_gloo=(a.backend != "nccl"))
     lam = synthetic_state(s, coords, pdims, seed=2 + rank)
     dt = 0.1 * min(dx) / ((2 * a.order + 1) * 3 * lam)
     work = s.work()
@@ -141,7 +149,7 @@ def main():
     sync()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     finite = bool(torch.isfinite(s.u).all().item())
