@@ -200,6 +200,106 @@ fv_rusanov_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt,
     }
 }
 
+// Large 3-D patches (cfg 4's limiter patch: 17^3 x 5 doubles = 196 KB with halo, more than LDS): the patch streams
+// plane by plane (axis 0) through a 4-slot LDS ring, filled with coalesced 16-byte loads one plane ahead; thread
+// (j, k) updates the volume (i, j, k) of the current plane from the ring.  The ring holds the OLD values, so the new
+// values of plane i go straight back to HBM in place: every plane is read once and its interior written once.
+template <class PDE, int MODE>
+__global__ void __launch_bounds__(256)
+fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h) {
+    extern __shared__ __attribute__((aligned(16))) double ring[];
+    const int S = P + 2 * H;
+    const int plane = S * S * V;                                  // doubles per plane
+    double* Qp = Q + (long)blockIdx.x * S * plane;
+    const int tid = threadIdx.x;
+    const int j = tid / P + H, k = tid % P + H;
+    const bool cell_ok = tid < P * P;
+    auto load_plane = [&](int i) {
+        const double* src = Qp + (long)i * plane;
+        double* dst = ring + (i & 3) * plane;
+        if (((reinterpret_cast<unsigned long long>(src) & 15) == 0) && (plane % 2 == 0)) {
+            for (int x = tid; x < plane / 2; x += 256) reinterpret_cast<double2*>(dst)[x] = reinterpret_cast<const double2*>(src)[x];
+        } else {
+            for (int x = tid; x < plane; x += 256) dst[x] = src[x];
+        }
+    };
+    load_plane(H - 1);
+    load_plane(H);
+    for (int i = H; i < P + H; i++) {
+        load_plane(i + 1);                                         // slot (i+1)&3 was last read in iteration i-3
+        __syncthreads();
+        if (cell_ok) {
+            const double* c0 = ring + (i & 3) * plane + (j * S + k) * V;
+            const double* nb[3][2] = {{ring + ((i - 1) & 3) * plane + (j * S + k) * V, ring + ((i + 1) & 3) * plane + (j * S + k) * V},
+                                      {c0 - S * V, c0 + S * V}, {c0 - V, c0 + V}};
+            const int co[3] = {i, j, k};
+            double qc[MAXV], out[MAXV];
+#pragma unroll
+            for (int v = 0; v < MAXV; v++) qc[v] = v < m ? c0[v] : 0.0;
+            if constexpr (MODE == 0) {
+                double acc[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) acc[v] = qc[v];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    double Fp[MAXV], Fm[MAXV], qP[MAXV], qM[MAXV];
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) { Fp[v] = 0.0; Fm[v] = 0.0; qP[v] = v < m ? nb[d][1][v] : 0.0; qM[v] = v < m ? nb[d][0][v] : 0.0; }
+                    if (co[d] + 1 < P + H) PDE::flux_rt(qP, d, Fp);
+                    if (co[d] - 1 >= H) PDE::flux_rt(qM, d, Fm);
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) acc[v] = acc[v] - 0.5 * Fp[v] + 0.5 * Fm[v];
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    double qP[MAXV], qM[MAXV];
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) { qP[v] = v < m ? nb[d][1][v] : 0.0; qM[v] = v < m ? nb[d][0][v] : 0.0; }
+                    const double lc = PDE::maxeig(qc, d);
+                    const double lp = (co[d] + 1 < P + H) ? PDE::maxeig(qP, d) : 0.0;
+                    const double lm = (co[d] - 1 >= H) ? PDE::maxeig(qM, d) : 0.0;
+                    const double mp = lp > lc ? lp : lc;
+                    const double mm = lm > lc ? lm : lc;
+                    acc[0] = 0.5 * dt * ((-qP[0] + qc[0]) * mp + (qM[0] - qc[0]) * mm) + acc[0];
+                }
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) out[v] = acc[v];
+            } else {
+                double acc[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) acc[v] = 0.0;
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    double qpp[MAXV], qmp[MAXV], Fc[MAXV], Fn[MAXV];
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) { qpp[v] = v < m ? nb[d][1][v] : 0.0; qmp[v] = v < m ? nb[d][0][v] : 0.0; Fc[v] = 0.0; Fn[v] = 0.0; }
+                    const double lc = PDE::maxeig(qc, d);
+                    const double sp = fmax(lc, PDE::maxeig(qpp, d));
+                    const double sm = fmax(PDE::maxeig(qmp, d), lc);
+                    PDE::flux_rt(qc, d, Fc);
+                    PDE::flux_rt(qpp, d, Fn);
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++)
+                        if (v < m) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sp * (qpp[v] - qc[v]);
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) Fn[v] = 0.0;
+                    PDE::flux_rt(qmp, d, Fn);
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++)
+                        if (v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qmp[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) out[v] = qc[v] - dt_over_h * acc[v];
+            }
+            double* dst = Qp + (long)i * plane + (j * S + k) * V;
+#pragma unroll
+            for (int v = 0; v < MAXV; v++)
+                if (v < m) dst[v] = out[v];
+        }
+        __syncthreads();                                           // plane i-1's slot may be refilled next iteration
+    }
+}
+
 template <class PDE>
 __global__ void pde_eval_kernel(int normal, long n, int stride, const double* __restrict__ Q, double* __restrict__ F,
                                 double* __restrict__ lam) {
@@ -235,6 +335,10 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1);
         else
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+    } else if (DIM == 3 && P * P <= 256 && (size_t)4 * S * S * V * sizeof(double) <= 64 * 1024) {
+        // plane-streaming variant: 4-plane LDS ring, one workgroup per patch
+        hipLaunchKernelGGL((fv_rusanov_slab_kernel<PDE, MODE>), dim3((unsigned)n_patches), dim3(256), (size_t)4 * S * S * V * sizeof(double), s,
+                           Q, P, H, m, V, dt, doh);
     } else if (ncell <= 4096) {
         hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
     }
