@@ -1,0 +1,340 @@
+// Stage A for the 3-D cells whose space-time image does not fit the LDS (N = 7, 8: p = 6, 7;
+// the image alone is 160 KiB at N = 8).  Same scheme and same results (to rounding) as
+// dg_stage_a_kernel; no counterpart in the reference.
+//
+// "Level-streamed" Picard loop.  The derivative sums S_l = sum_d (1/dx_d) D_d f_d(q_l) of a time level l
+// need only q_l, and the time update q_l' = u - dt sum_l T[l'][l] S_l is linear in them.  So an iteration
+// walks over the time levels two at a time:
+//   load    q_l of the two levels from the workgroup's slab (L2/MALL-resident), flux scalars once per node -> LDS
+//   derive  the three directions at once on 12 waves, pencil tasks split by rows (two half tasks per pencil
+//           keep the partial sums at 40 VGPRs):  y -> A, z -> B, x holds and stores over Q after the barrier
+//   fold    node owners (node, half of the output levels) add T[l'][l] * (S_x + S_y + S_z) into register
+//           accumulators -- the output-stationary form of the time contraction
+// and ends with q_l' = u - dt * acc, written back to the slab (the last iteration keeps it in registers for
+// the time averages).  Per iteration and cell the slab traffic is one read and one write of q (160 KiB each
+// at N = 8) instead of every partial sum (the scratch variant), and LDS holds two levels, not eight.
+//
+// LDS strides: odd row stride (N = 8: 9) and plane stride = 8 mod 32 doubles keep the y and z pencils
+// conflict-free for 32-lane ds_read_b64 groups (scripts/lds_stride_search.py model); x pencils and the
+// node-linear phases pay ~1 extra pass per wave instruction.
+#pragma once
+#include "exa_dg_kernels.hpp"
+
+namespace exa {
+
+// Opaque copies: values derived from them cannot be hoisted out of the step loop (the compiler otherwise
+// precomputes every address and predicate of every phase once per kernel and spills them -- 324 VGPRs).
+__device__ inline int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ inline int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+
+template <int N> struct StreamGeo {
+    static constexpr int NN = N * N * N, NF = N * N;
+    static constexpr int PY = (N % 2 == 0) ? N + 1 : N;      // row stride
+    static constexpr int PX = N * PY;                         // plane stride
+    static constexpr int SL = N * PX;                         // one (var, level) image
+    __device__ static inline int node_off(int n) { return (n / NF) * PX + ((n / N) % N) * PY + n % N; }
+    __device__ static constexpr int pstride(int d) { return d == 0 ? PX : (d == 1 ? PY : 1); }
+    // first node of pencil t (t = lexicographic index of the remaining axes = face-node index of the traces)
+    __device__ static inline int pbase(int d, int t) {
+        const int a = t / N, b = t - a * N;
+        return d == 0 ? a * PY + b : (d == 1 ? a * PX + b : a * PX + b * PY);
+    }
+};
+
+template <int N, class PDE> struct StageAStream {
+    using G = StreamGeo<N>;
+    static constexpr int NV = PDE::NV, NA = PDE::NAUX;
+    static constexpr int LG = 2;                              // time levels per step
+    static constexpr int HR = (N + 1) / 2;                    // rows of a half task
+    static constexpr int LH = (N + 1) / 2;                    // output levels of a node owner
+    static constexpr int QSZ = NV * LG * G::SL;               // Q, A, B
+    static constexpr int AXO = 3 * QSZ;                       // flux scalars [a][level][node]
+    static constexpr int PIC_D = 3 * QSZ + NA * LG * G::SL;   // Picard phases
+    static constexpr int FIN_D = 4 * NV * G::SL;              // final phases: qbar, Fbar_x, Fbar_y, Fbar_z
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(PIC_D > FIN_D ? PIC_D : FIN_D);
+    static constexpr int TH = LG * G::NF;                     // pencils per direction and step
+    static constexpr int HW = ((TH + 63) / 64) * 64;          // lanes of one half of a direction group (wave-aligned)
+    static constexpr int GW = 2 * HW;                         // lanes of a direction group: two half tasks per pencil
+    static constexpr int OWNH = ((G::NN + 63) / 64) * 64;     // lanes of an owner half (wave-aligned)
+    static constexpr int NT = (3 * GW > 2 * OWNH) ? 3 * GW : 2 * OWNH;
+    static constexpr size_t SLAB_D = (size_t)NV * N * G::NN;  // doubles of slab per workgroup: q[level][var][node]
+};
+
+template <int N, class PDE>
+__global__ void __launch_bounds__((StageAStream<N, PDE>::NT))
+dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
+                         long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
+                         const void* __restrict__ ops_raw, double* __restrict__ slab) {
+    using G = StreamGeo<N>;
+    using SA = StageAStream<N, PDE>;
+    constexpr int NV = PDE::NV, NA = PDE::NAUX, DIM = 3;
+    constexpr int NN = G::NN, NF = G::NF, SL = G::SL;
+    constexpr int LG = SA::LG, HR = SA::HR, LH = SA::LH, QSZ = SA::QSZ, AXO = SA::AXO;
+    constexpr int NT = SA::NT, TH = SA::TH, HW = SA::HW, GW = SA::GW, OWNH = SA::OWNH;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+
+    const int tid = threadIdx.x;
+    const double idx[3] = {idx0, idx1, idx2};
+    double* qs = slab + (size_t)blockIdx.x * SA::SLAB_D;
+
+    // derivative role: direction group, half task (half, level slot, pencil)
+    const int grp = __builtin_amdgcn_readfirstlane(tid / GW);
+    const int bt = tid - grp * GW;
+    const int d_half = __builtin_amdgcn_readfirstlane(bt / HW);             // wave-uniform: selects the rows of D
+    const int d_r = bt - d_half * HW;
+    const int d_ls = d_r / NF, d_t = d_r - d_ls * NF;
+    const bool d_task = grp < DIM && d_r < TH;
+    // owner role: node, half of the output levels; loader role: node, level slot (same split)
+    const int o_h = __builtin_amdgcn_readfirstlane(tid / OWNH);
+    const int o_n = tid - o_h * OWNH;
+    const bool owner = o_h < 2 && o_n < NN;
+    const int o_off0 = G::node_off(o_n < NN ? o_n : 0);
+
+    for (long b = blockIdx.x; b < box.nbox; b += gridDim.x) {
+        const long cell = box.cell(b);
+        double acc[LH][NV];                                      // time-update accumulators, then the final iterate
+#pragma unroll
+        for (int k = 0; k < LH; k++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) acc[k][v] = 0.0;
+
+        for (int it = 0; it < n_it; it++) {
+            // iteration 0: the iterate is constant in time -- one level, row sums of T
+            const int ngroups = it == 0 ? 1 : (N + LG - 1) / LG;
+            for (int g = 0; g < ngroups; g++) {
+                const int nl = it == 0 ? 1 : (N - g * LG < LG ? N - g * LG : LG);
+                // ---- load: q of the level (node-contiguous in the slab), flux scalars once per node
+                if (owner && o_h < nl) {
+                    double q[NV], a[NA];
+                    const int l = g * LG + o_h;
+                    const int o_off = opaque_v(o_off0) + opaque_s(o_h) * SL;
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+                        q[v] = it == 0 ? u_in[(cell * NN + o_n) * NV + v] : qs[((size_t)l * NV + v) * NN + o_n];
+                    PDE::aux_fast(q, a);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) lds[v * LG * SL + o_off] = q[v];
+#pragma unroll
+                    for (int k = 0; k < NA; k++) lds[AXO + k * LG * SL + o_off] = a[k];
+                }
+                __syncthreads();
+                // ---- derive: half task = rows [half*HR, half*HR + HR) of one pencil, all variables
+                double s[HR][NV];
+                bool hold = false;
+                int hoff = 0;
+                static_for<0, DIM>([&](auto dc) {
+                    constexpr int D = decltype(dc)::value;
+                    if (d_task && grp == D && d_ls < nl) {
+                        constexpr int ps = G::pstride(D);
+                        const int half = opaque_s(d_half);
+                        const EXA_AS4 double* Dcol = ops_here<N>(ops_raw)->DT + half * HR;     // DT[j][half*HR + i]
+                        const int off = opaque_v(d_ls * SL + G::pbase(D, d_t));
+                        const int soff = off + half * (HR * ps);                               // first row of this half
+#pragma unroll
+                        for (int i = 0; i < HR; i++)
+#pragma unroll
+                            for (int v = 0; v < NV; v++) s[i][v] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; j++) {
+                            double q[NV], a[NA], F[NV];
+#pragma unroll
+                            for (int v = 0; v < NV; v++) q[v] = lds[off + v * LG * SL + j * ps];
+#pragma unroll
+                            for (int k = 0; k < NA; k++) a[k] = lds[AXO + off + k * LG * SL + j * ps];
+                            PDE::template flux_scaled<D>(q, a, idx[D], F);
+#pragma unroll
+                            for (int i = 0; i < HR; i++) {
+                                const double dij = Dcol[j * N + i];
+#pragma unroll
+                                for (int v = 0; v < NV; v++) s[i][v] += dij * F[v];
+                            }
+                        }
+                        if constexpr (D > 0) {
+#pragma unroll
+                            for (int i = 0; i < HR; i++)
+                                if (N % 2 == 0 || i + 1 < HR || half == 0) {                   // odd N: the second half has one row less
+#pragma unroll
+                                    for (int v = 0; v < NV; v++) lds[D * QSZ + soff + v * LG * SL + i * ps] = s[i][v];
+                                }
+                        } else {
+                            hold = true;
+                            hoff = soff;
+                        }
+                    }
+                });
+                __syncthreads();
+                if (hold) {                                      // every read of Q is done: Q := S_x
+                    constexpr int ps = G::pstride(0);
+#pragma unroll
+                    for (int i = 0; i < HR; i++)
+                        if (N % 2 == 0 || i + 1 < HR || d_half == 0) {
+#pragma unroll
+                            for (int v = 0; v < NV; v++) lds[hoff + v * LG * SL + i * ps] = s[i][v];
+                        }
+                }
+                __syncthreads();
+                // ---- fold: acc[l'] += T[l'][l] * S_l for the levels of this step
+                if (owner) {
+                    const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+                    const int lp0 = opaque_s(o_h) * LH;
+                    for (int ls = 0; ls < nl; ls++) {
+                        const int l = g * LG + ls;
+                        const int o_off = opaque_v(o_off0) + ls * SL;
+                        double S[NV];
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            const int p = v * LG * SL + o_off;
+                            S[v] = lds[p] + lds[p + QSZ] + lds[p + 2 * QSZ];
+                        }
+#pragma unroll
+                        for (int k = 0; k < LH; k++) {
+                            const int lp = lp0 + k;
+                            if (N % 2 == 0 || k + 1 < LH || lp < N) {
+                                const double tl = it == 0 ? o->Tsum[lp] : o->T[lp * N + l];
+#pragma unroll
+                                for (int v = 0; v < NV; v++) acc[k][v] = (g == 0 && ls == 0) ? tl * S[v] : acc[k][v] + tl * S[v];
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- new iterate q_l' = u - dt * acc
+            if (owner) {
+                double un[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) un[v] = u_in[(cell * NN + o_n) * NV + v];
+#pragma unroll
+                for (int k = 0; k < LH; k++) {
+                    const int lp = o_h * LH + k;
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        acc[k][v] = un[v] - dt * acc[k][v];
+                        if (lp < N && it + 1 < n_it) qs[((size_t)lp * NV + v) * NN + o_n] = acc[k][v];
+                    }
+                }
+            }
+            if (it + 1 < n_it) {
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+
+        // ---- time averages: each owner over its levels, the two halves meet in LDS (qbar | Fbar_d)
+        {
+            double qb[NV], Fb[DIM][NV];
+            const int o_off = opaque_v(o_off0);
+            if (owner) {
+                const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
+#pragma unroll
+                for (int v = 0; v < NV; v++) qb[v] = 0.0;
+#pragma unroll
+                for (int d = 0; d < DIM; d++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) Fb[d][v] = 0.0;
+                if (n_it > 0) {
+#pragma unroll
+                    for (int k = 0; k < LH; k++) {
+                        const int lp = o_h * LH + k;
+                        if (lp < N) {
+                            double a[NA], F[NV];
+                            PDE::aux_fast(acc[k], a);
+                            const double wl = wm[lp];
+#pragma unroll
+                            for (int v = 0; v < NV; v++) qb[v] += wl * acc[k][v];
+                            static_for<0, DIM>([&](auto dc) {
+                                constexpr int D = decltype(dc)::value;
+                                PDE::template flux<D>(acc[k], a, F);
+#pragma unroll
+                                for (int v = 0; v < NV; v++) Fb[D][v] += wl * F[v];
+                            });
+                        }
+                    }
+                } else if (o_h == 0) {                           // single stage: qbar = u, Fbar = F(u)
+                    double un[NV], a[NA];
+#pragma unroll
+                    for (int v = 0; v < NV; v++) un[v] = u_in[(cell * NN + o_n) * NV + v];
+                    PDE::aux_fast(un, a);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) qb[v] = un[v];
+                    static_for<0, DIM>([&](auto dc) {
+                        constexpr int D = decltype(dc)::value;
+                        PDE::template flux<D>(un, a, Fb[D]);
+                    });
+                }
+                if (o_h == 1) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        lds[v * SL + o_off] = qb[v];
+#pragma unroll
+                        for (int d = 0; d < DIM; d++) lds[((1 + d) * NV + v) * SL + o_off] = Fb[d][v];
+                    }
+                }
+            }
+            __syncthreads();
+            if (owner && o_h == 0) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    lds[v * SL + o_off] += qb[v];
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) lds[((1 + d) * NV + v) * SL + o_off] += Fb[d][v];
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- volume integral (in place over Fbar_d) + face extrapolation: pencil tasks (d, v, t), t fastest
+        {
+            const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+            for (int task = tid; task < DIM * NV * NF; task += NT) {
+                const int d = task / (NV * NF);
+                const int r = task - d * (NV * NF);
+                const int v = r / NF, t = r - v * NF;
+                const int ps = G::pstride(d);
+                const int pb = G::pbase(d, t);
+                double qb[N], Fb[N];
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    qb[j] = lds[v * SL + pb + j * ps];
+                    Fb[j] = lds[((1 + d) * NV + v) * SL + pb + j * ps];
+                }
+                const double sc = dt * idx[d];
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    double sv = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; j++) sv += o->Kxi[i * N + j] * Fb[j];
+                    lds[((1 + d) * NV + v) * SL + pb + i * ps] = sc * o->iw[i] * sv;
+                }
+                double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    qL += o->phiL[j] * qb[j];
+                    qR += o->phiR[j] * qb[j];
+                    FL += o->phiL[j] * Fb[j];
+                    FR += o->phiR[j] * Fb[j];
+                }
+                double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
+                double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
+                tl[(0 * NV + v) * NF + t] = qL;
+                tl[(1 * NV + v) * NF + t] = FL;
+                tr[(0 * NV + v) * NF + t] = qR;
+                tr[(1 * NV + v) * NF + t] = FR;
+            }
+        }
+        __syncthreads();
+
+        // ---- u* = u + sum_d vol_d, AoS (coalesced)
+        for (int e = tid; e < NN * NV; e += NT) {
+            const int n = e / NV, v = e - n * NV;
+            const int off = G::node_off(n);
+            double us = u_in[cell * (NN * NV) + e];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) us += lds[((1 + d) * NV + v) * SL + off];
+            u_out[cell * (NN * NV) + e] = us;
+        }
+        __syncthreads();                                         // LDS is reused by the next cell
+    }
+}
+
+}  // namespace exa

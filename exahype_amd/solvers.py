@@ -137,8 +137,8 @@ class HaloExchange:
     (CUDA with the nccl/RCCL backend; CPU with gloo for the rehearsal tests).
 
     trace: tensor [dim, 2, nc0, nc1, nc2, TS]; ghosts[d*2+s]: [transverse cells, TS].
-    Message order per peer is fixed so that two messages between the same pair of
-    ranks (process grid extent 2) match without tags as well."""
+    A process grid of extent 2 in a direction (both neighbours are the same rank) sends one
+    message per peer holding both layers; larger extents send one layer to each neighbour."""
 
     def __init__(self, part, nc, ts, device, dtype=None, stage_through_host=False):
         torch = _torch()
@@ -147,12 +147,18 @@ class HaloExchange:
         dtype = dtype or torch.float64
         self.ghost = [None] * 6
         self.send = [None] * 6
+        # per partitioned direction one contiguous pair buffer each way, so that a process grid of extent 2
+        # (both neighbours are the same rank: every case at 2, 4 and 8 GPUs) needs ONE message per peer:
+        #   send pair = (my L layer, my R layer);  ghost pair = (peer's L layer -> my high ghost, peer's R -> my low)
+        self._send_pair = [None] * 3
+        self._ghost_pair = [None] * 3
         for d in range(part.dim):
             if part.partitioned(d):
                 nt = int(np.prod(self.nc)) // self.nc[d]
-                for s in range(2):
-                    self.ghost[d * 2 + s] = torch.zeros(nt, ts, dtype=dtype, device=device)
-                    self.send[d * 2 + s] = torch.zeros(nt, ts, dtype=dtype, device=device)
+                self._send_pair[d] = torch.zeros(2, nt, ts, dtype=dtype, device=device)
+                self._ghost_pair[d] = torch.zeros(2, nt, ts, dtype=dtype, device=device)
+                self.send[d * 2 + 0], self.send[d * 2 + 1] = self._send_pair[d][0], self._send_pair[d][1]
+                self.ghost[d * 2 + 1], self.ghost[d * 2 + 0] = self._ghost_pair[d][0], self._ghost_pair[d][1]
 
     def pack(self, trace):
         for d in range(self.part.dim):
@@ -171,15 +177,23 @@ class HaloExchange:
             if not self.part.partitioned(d):
                 continue
             lo_n, hi_n = self.part.neighbour(d, -1), self.part.neighbour(d, +1)
+            if lo_n == hi_n:                           # extent 2: one message per peer, both layers
+                sp, gp = self._send_pair[d], self._ghost_pair[d]
+                if self.stage:                         # gloo rehearsal with device tensors: go through host copies
+                    hp = gp.cpu()
+                    self._staged.append((gp, hp))
+                    sp, gp = sp.cpu(), hp
+                ops += [dist.P2POp(dist.isend, sp, lo_n, tag=2 * d), dist.P2POp(dist.irecv, gp, lo_n, tag=2 * d)]
+                continue
             s_lo, s_hi = self.send[d * 2 + 0], self.send[d * 2 + 1]
             g_lo, g_hi = self.ghost[d * 2 + 0], self.ghost[d * 2 + 1]
-            if self.stage:   # gloo rehearsal with device tensors: go through host copies
+            if self.stage:
                 s_lo, s_hi = s_lo.cpu(), s_hi.cpu()
                 h_lo, h_hi = g_lo.cpu(), g_hi.cpu()
                 self._staged += [(g_lo, h_lo), (g_hi, h_hi)]
                 g_lo, g_hi = h_lo, h_hi
             # my L layer -> low neighbour (its high ghost); my R layer -> high neighbour (its low ghost).
-            # receives are posted in the order the peer sends (its L layer first).
+            # receives are posted in the order the peers send.
             ops += [dist.P2POp(dist.isend, s_lo, lo_n, tag=2 * d), dist.P2POp(dist.isend, s_hi, hi_n, tag=2 * d + 1),
                     dist.P2POp(dist.irecv, g_hi, hi_n, tag=2 * d), dist.P2POp(dist.irecv, g_lo, lo_n, tag=2 * d + 1)]
         self._reqs = dist.batch_isend_irecv(ops) if ops else []

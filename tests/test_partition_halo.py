@@ -79,7 +79,7 @@ print("rank", rank, "ok")
 '''
 
 
-@pytest.mark.parametrize("world,pdims", [(2, [2, 1, 1]), (2, [1, 1, 2]), (4, [2, 2, 1])])
+@pytest.mark.parametrize("world,pdims", [(2, [2, 1, 1]), (2, [1, 1, 2]), (4, [2, 2, 1]), (3, [1, 3, 1]), (8, [2, 2, 2])])
 def test_halo_exchange_gloo(tmp_path, world, pdims):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(root=ROOT, pdims=pdims))
