@@ -11,8 +11,10 @@
 //   fold    node owners (node, half of the output levels) add T[l'][l] * (S_x + S_y + S_z) into register
 //           accumulators -- the output-stationary form of the time contraction
 // and ends with q_l' = u - dt * acc, written back to the slab (the last iteration keeps it in registers for
-// the time averages).  Per iteration and cell the slab traffic is one read and one write of q (160 KiB each
-// at N = 8) instead of every partial sum (the scratch variant), and LDS holds two levels, not eight.
+// the time averages).  A step takes the levels g and LH + g, so that the lane that loads a level is the lane
+// that produced it: slab traffic is lane-private (no fence), fetched one step ahead of its use, and the first
+// level of each half never leaves the registers.  Per iteration and cell that is 3/4 of q written and read
+// (120 KiB each way at N = 8) instead of every partial sum (the scratch variant); LDS holds two levels, not eight.
 //
 // LDS strides: odd row stride (N = 8: 9) and plane stride = 8 mod 32 doubles keep the y and z pencils
 // conflict-free for 32-lane ds_read_b64 groups (scripts/lds_stride_search.py model); x pencils and the
@@ -57,6 +59,7 @@ template <int N, class PDE> struct StageAStream {
     static constexpr int GW = 2 * HW;                         // lanes of a direction group: two half tasks per pencil
     static constexpr int OWNH = ((G::NN + 63) / 64) * 64;     // lanes of an owner half (wave-aligned)
     static constexpr int NT = (3 * GW > 2 * OWNH) ? 3 * GW : 2 * OWNH;
+    static constexpr int SKEW_SLEEP = 32;                     // x 64 cycles x 32 slots ~ one iteration
     static constexpr size_t SLAB_D = (size_t)NV * N * G::NN;  // doubles of slab per workgroup: q[level][var][node]
 };
 
@@ -74,6 +77,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
     const int tid = threadIdx.x;
+    EXA_STAMP_INIT();
     const double idx[3] = {idx0, idx1, idx2};
     double* qs = slab + (size_t)blockIdx.x * SA::SLAB_D;
 
@@ -90,34 +94,57 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
     const bool owner = o_h < 2 && o_n < NN;
     const int o_off0 = G::node_off(o_n < NN ? o_n : 0);
 
+    // Start the workgroups of an XCD staggered over roughly one Picard iteration: they all do the same work, so
+    // without it every CU writes its share of the slab in the same microsecond (31 MB chip-wide at N = 8) and the
+    // bursts, not the average (~2 TB/s), set the pace.  Costs one iteration's time once per launch.
+    for (int k = (blockIdx.x >> 3) & 31; k > 0; k--) __builtin_amdgcn_s_sleep(SA::SKEW_SLEEP);
+
     for (long b = blockIdx.x; b < box.nbox; b += gridDim.x) {
         const long cell = box.cell(b);
         double acc[LH][NV];                                      // time-update accumulators, then the final iterate
+        double nxt[NV];                                          // what the next load phase needs, fetched a step ahead
 #pragma unroll
         for (int k = 0; k < LH; k++)
 #pragma unroll
             for (int v = 0; v < NV; v++) acc[k][v] = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) nxt[v] = owner ? u_in[(cell * NN + o_n) * NV + v] : 1.0;
 
         for (int it = 0; it < n_it; it++) {
-            // iteration 0: the iterate is constant in time -- one level, row sums of T
-            const int ngroups = it == 0 ? 1 : (N + LG - 1) / LG;
+            // iteration 0: the iterate is constant in time -- one level, row sums of T.  Later iterations: step g
+            // takes the levels g and LH + g, i.e. the level with index g of either owner half -- every lane loads
+            // what it wrote itself (no fence), a step ahead of its use (the slab latency hides under a whole step).
+            const int ngroups = it == 0 ? 1 : LH;
             for (int g = 0; g < ngroups; g++) {
-                const int nl = it == 0 ? 1 : (N - g * LG < LG ? N - g * LG : LG);
-                // ---- load: q of the level (node-contiguous in the slab), flux scalars once per node
+                const int nl = it == 0 ? 1 : (LH + g < N ? 2 : 1);
+                // ---- load: q of the level, flux scalars once per node
                 if (owner && o_h < nl) {
-                    double q[NV], a[NA];
-                    const int l = g * LG + o_h;
+                    double a[NA];
                     const int o_off = opaque_v(o_off0) + opaque_s(o_h) * SL;
+                    PDE::aux_fast(nxt, a);
 #pragma unroll
-                    for (int v = 0; v < NV; v++)
-                        q[v] = it == 0 ? u_in[(cell * NN + o_n) * NV + v] : qs[((size_t)l * NV + v) * NN + o_n];
-                    PDE::aux_fast(q, a);
-#pragma unroll
-                    for (int v = 0; v < NV; v++) lds[v * LG * SL + o_off] = q[v];
+                    for (int v = 0; v < NV; v++) lds[v * LG * SL + o_off] = nxt[v];
 #pragma unroll
                     for (int k = 0; k < NA; k++) lds[AXO + k * LG * SL + o_off] = a[k];
                 }
+                if (owner) {                                     // fetch ahead: the next level of this lane, or u for the update
+                    const int ln = opaque_s(o_h) * LH + g + 1;
+                    const int n = opaque_v(o_n);
+                    if (g + 1 < ngroups) {
+                        if (ln < N) {
+                            const double* row = qs + (size_t)ln * NV * NN;       // uniform base + lane offset: saddr loads
+#pragma unroll
+                            for (int v = 0; v < NV; v++) nxt[v] = row[v * NN + n];
+                        }
+                    } else {
+                        const double* un = u_in + (cell * NN + n) * NV;
+#pragma unroll
+                        for (int v = 0; v < NV; v++) nxt[v] = un[v];
+                    }
+                }
+                EXA_STAMP(0);
                 __syncthreads();
+                EXA_STAMP(1);
                 // ---- derive: half task = rows [half*HR, half*HR + HR) of one pencil, all variables
                 double s[HR][NV];
                 bool hold = false;
@@ -162,7 +189,9 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         }
                     }
                 });
+                EXA_STAMP(2);
                 __syncthreads();
+                EXA_STAMP(3);
                 if (hold) {                                      // every read of Q is done: Q := S_x
                     constexpr int ps = G::pstride(0);
 #pragma unroll
@@ -172,52 +201,73 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                             for (int v = 0; v < NV; v++) lds[hoff + v * LG * SL + i * ps] = s[i][v];
                         }
                 }
+                EXA_STAMP(4);
                 __syncthreads();
+                EXA_STAMP(5);
                 // ---- fold: acc[l'] += T[l'][l] * S_l for the levels of this step
                 if (owner) {
-                    const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+                    // T and Tsum are adjacent in DgOps: one scalar-indexed array serves both (a select between two
+                    // pointers turns the coefficient into a serialised vector load)
+                    const EXA_AS4 double* Tm = ops_here<N>(ops_raw)->T;
                     const int lp0 = opaque_s(o_h) * LH;
-                    for (int ls = 0; ls < nl; ls++) {
-                        const int l = g * LG + ls;
-                        const int o_off = opaque_v(o_off0) + ls * SL;
-                        double S[NV];
+                    const int o_off = opaque_v(o_off0);
+                    if (g == 0) {
 #pragma unroll
-                        for (int v = 0; v < NV; v++) {
-                            const int p = v * LG * SL + o_off;
-                            S[v] = lds[p] + lds[p + QSZ] + lds[p + 2 * QSZ];
-                        }
+                        for (int k = 0; k < LH; k++)
 #pragma unroll
-                        for (int k = 0; k < LH; k++) {
-                            const int lp = lp0 + k;
-                            if (N % 2 == 0 || k + 1 < LH || lp < N) {
-                                const double tl = it == 0 ? o->Tsum[lp] : o->T[lp * N + l];
+                            for (int v = 0; v < NV; v++) acc[k][v] = 0.0;
+                    }
 #pragma unroll
-                                for (int v = 0; v < NV; v++) acc[k][v] = (g == 0 && ls == 0) ? tl * S[v] : acc[k][v] + tl * S[v];
+                    for (int ls = 0; ls < LG; ls++) {
+                        if (ls < nl) {
+                            const int l = ls * LH + g;
+                            double S[NV], tl[LH];
+#pragma unroll
+                            for (int k = 0; k < LH; k++) {
+                                const int lp = (N % 2 == 0 || k + 1 < LH || lp0 + k < N) ? lp0 + k : 0;
+                                tl[k] = Tm[__builtin_amdgcn_readfirstlane(it == 0 ? N * N + lp : lp * N + l)];
                             }
+                            double Sx[NV], Sy[NV], Sz[NV];
+#pragma unroll
+                            for (int v = 0; v < NV; v++) {
+                                const int p = (v * LG + ls) * SL + o_off;
+                                Sx[v] = lds[p];
+                                Sy[v] = lds[p + QSZ];
+                                Sz[v] = lds[p + 2 * QSZ];
+                            }
+#pragma unroll
+                            for (int v = 0; v < NV; v++) S[v] = Sx[v] + Sy[v] + Sz[v];
+#pragma unroll
+                            for (int k = 0; k < LH; k++)
+#pragma unroll
+                                for (int v = 0; v < NV; v++) acc[k][v] += tl[k] * S[v];
                         }
                     }
                 }
+                EXA_STAMP(6);
                 __syncthreads();
+                EXA_STAMP(7);
             }
-            // ---- new iterate q_l' = u - dt * acc
+            // ---- new iterate q_l' = u - dt * acc (u arrived in nxt); level 0 of this lane feeds the next load phase
+            // from registers, the others wait in the slab
             if (owner) {
-                double un[NV];
-#pragma unroll
-                for (int v = 0; v < NV; v++) un[v] = u_in[(cell * NN + o_n) * NV + v];
+                const int lp0 = opaque_s(o_h) * LH;
+                const int n = opaque_v(o_n);
+                const bool keep = it + 1 < n_it;
 #pragma unroll
                 for (int k = 0; k < LH; k++) {
-                    const int lp = o_h * LH + k;
 #pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        acc[k][v] = un[v] - dt * acc[k][v];
-                        if (lp < N && it + 1 < n_it) qs[((size_t)lp * NV + v) * NN + o_n] = acc[k][v];
+                    for (int v = 0; v < NV; v++) acc[k][v] = nxt[v] - dt * acc[k][v];
+                    if (k > 0 && keep && (N % 2 == 0 || k + 1 < LH || lp0 + k < N)) {
+                        double* row = qs + (size_t)(lp0 + k) * NV * NN;          // uniform base + lane offset: saddr stores
+#pragma unroll
+                        for (int v = 0; v < NV; v++) row[v * NN + n] = acc[k][v];
                     }
                 }
+#pragma unroll
+                for (int v = 0; v < NV; v++) nxt[v] = acc[0][v];
             }
-            if (it + 1 < n_it) {
-                __threadfence_block();
-                __syncthreads();
-            }
+            EXA_STAMP(8);
         }
 
         // ---- time averages: each owner over its levels, the two halves meet in LDS (qbar | Fbar_d)
@@ -282,6 +332,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
             }
             __syncthreads();
         }
+        EXA_STAMP(9);
 
         // ---- volume integral (in place over Fbar_d) + face extrapolation: pencil tasks (d, v, t), t fastest
         {
@@ -323,6 +374,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
             }
         }
         __syncthreads();
+        EXA_STAMP(10);
 
         // ---- u* = u + sum_d vol_d, AoS (coalesced)
         for (int e = tid; e < NN * NV; e += NT) {
@@ -334,7 +386,9 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
             u_out[cell * (NN * NV) + e] = us;
         }
         __syncthreads();                                         // LDS is reused by the next cell
+        EXA_STAMP(11);
     }
+    EXA_STAMP_FLUSH();
 }
 
 }  // namespace exa
