@@ -449,247 +449,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 }
 
 // ------------------------------------------------------------------------------------------
-// Stage A, scratch variant: cell images that do not fit the 160 KiB LDS (3-D N = 7, 8: p = 6, 7)
-// ------------------------------------------------------------------------------------------
-// Functional fallback, not tuned: the simple sequential-direction structure (partial sums by
-// read-modify-write, cached flux scalars) with the cell image in a per-workgroup slab of global memory
-// that stays L2/MALL-resident, and a persistent grid.  Same results as the LDS kernel to rounding.
-template <int DIM, int N, class PDE, int CPB> struct StageAScratch {
-    using G = Geo<DIM, N>;
-    static constexpr int NV = PDE::NV;
-    static constexpr int NA = PDE::NAUX;
-    static constexpr int ASZ = NV * G::NTS * G::SL;         // one q-sized array
-    static constexpr int AXO = 2 * ASZ;                      // aux offset inside a cell image
-    static constexpr int CS = 2 * ASZ + NA * N * G::SL;      // doubles per cell image
-    static constexpr size_t LDS_BYTES = (size_t)CPB * CS * sizeof(double);
-};
-
-template <int DIM, int N, class PDE, int CPB, int NT>
-__global__ void __launch_bounds__(NT)
-dg_stage_a_scratch_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
-                          long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it, DgOps<N> ops,
-                          double* __restrict__ scratch) {
-    using G = Geo<DIM, N>;
-    using SA = StageAScratch<DIM, N, PDE, CPB>;
-    constexpr int NV = PDE::NV, NA = PDE::NAUX;
-    constexpr int NN = G::NN, NF = G::NF, SL = G::SL, NTS = G::NTS;
-    constexpr int ASZ = SA::ASZ, AXO = SA::AXO, CS = SA::CS;
-    constexpr int KMAX = (CPB * NN + NT - 1) / NT;           // node tasks per thread
-    // cell image in this workgroup's slab of HBM/L2 scratch instead of LDS (visible to the whole workgroup
-    // across __syncthreads(): workgroup-scope release/acquire on one CU's write-through L1)
-    double* lds = scratch + (size_t)blockIdx.x * (size_t)CPB * CS;
-
-    const int tid = threadIdx.x;
-    const double idx[3] = {idx0, idx1, idx2};
-    // persistent grid: every workgroup walks over box slots b0, b0 + gridDim.x * CPB, ...
-    for (long b0 = (long)blockIdx.x * CPB; b0 < box.nbox; b0 += (long)gridDim.x * CPB) {
-    // box slot -> cell of the local block (-1: past the end of the box)
-    auto cell_of = [&](int c) -> long { return box.cell(b0 + c); };
-
-    // ---- load u (AoS, coalesced: consecutive lanes -> consecutive nodes), keep it in registers
-    double ur[KMAX][NV];
-#pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        const int task = tid + k * NT;
-        const int c = task / NN, n = task - c * NN;
-        const long cell = task < CPB * NN ? cell_of(c) : -1;
-#pragma unroll
-        for (int v = 0; v < NV; v++) ur[k][v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
-        if (task < CPB * NN && n_it > 0) {
-            const int off = c * CS + G::node_off(n);
-            double a[NA];
-            PDE::aux(ur[k], a);
-#pragma unroll
-            for (int l = 0; l < N; l++) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) lds[off + (v * NTS + l) * SL] = ur[k][v];
-#pragma unroll
-                for (int i = 0; i < NA; i++) lds[off + AXO + (i * N + l) * SL] = a[i];
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- Picard iterations (A.2):  q <- u - dt * T * sum_d (1/dx_d) D_d f_d(q)
-    for (int it = 0; it < n_it; it++) {
-        static_for<0, DIM>([&](auto dc) {
-            constexpr int D = decltype(dc)::value;
-            constexpr int ps = G::pstride(D);
-            for (int task = tid; task < CPB * N * NF; task += NT) {
-                const int c = task / (N * NF), r = task - c * (N * NF);
-                const int l = r / NF, t = r - l * NF;
-                const int off = c * CS + l * SL + G::pbase(D, t);
-                double F[N][NV];
-#pragma unroll
-                for (int j = 0; j < N; j++) {
-                    double q[NV], a[NA];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) q[v] = lds[off + v * NTS * SL + j * ps];
-#pragma unroll
-                    for (int i = 0; i < NA; i++) a[i] = lds[off + AXO + i * N * SL + j * ps];
-                    PDE::template flux<D>(q, a, F[j]);
-                }
-#pragma unroll
-                for (int i = 0; i < N; i++) {
-#pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int j = 0; j < N; j++) s += ops.D[i * N + j] * F[j][v];
-                        s *= idx[D];
-                        double* dst = &lds[off + ASZ + v * NTS * SL + i * ps];
-                        if constexpr (D == 0) *dst = s;
-                        else *dst += s;
-                    }
-                }
-            }
-            __syncthreads();
-        });
-        // time contraction per node, new cached scalars
-#pragma unroll
-        for (int k = 0; k < KMAX; k++) {
-            const int task = tid + k * NT;
-            if (task < CPB * NN) {
-                const int c = task / NN, n = task - c * NN;
-                const int off = c * CS + G::node_off(n);
-                double qn[N][NV];
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    double S[N];
-#pragma unroll
-                    for (int l = 0; l < N; l++) S[l] = lds[off + ASZ + (v * NTS + l) * SL];
-#pragma unroll
-                    for (int lp = 0; lp < N; lp++) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int l = 0; l < N; l++) acc += ops.T[lp * N + l] * S[l];
-                        qn[lp][v] = ur[k][v] - dt * acc;
-                        lds[off + (v * NTS + lp) * SL] = qn[lp][v];
-                    }
-                }
-#pragma unroll
-                for (int lp = 0; lp < N; lp++) {
-                    double a[NA];
-                    PDE::aux(qn[lp], a);
-#pragma unroll
-                    for (int i = 0; i < NA; i++) lds[off + AXO + (i * N + lp) * SL] = a[i];
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- time averages (A.3) per node: qbar -> B slab 0, Fbar_d -> B slab 1+d, u -> A slab 0
-#pragma unroll
-    for (int k = 0; k < KMAX; k++) {
-        const int task = tid + k * NT;
-        if (task < CPB * NN) {
-            const int c = task / NN, n = task - c * NN;
-            const int off = c * CS + G::node_off(n);
-            double qb[NV], Fb[DIM][NV];
-#pragma unroll
-            for (int v = 0; v < NV; v++) qb[v] = 0.0;
-#pragma unroll
-            for (int d = 0; d < DIM; d++)
-#pragma unroll
-                for (int v = 0; v < NV; v++) Fb[d][v] = 0.0;
-            if (n_it > 0) {
-#pragma unroll
-                for (int l = 0; l < N; l++) {
-                    double q[NV], a[NA], F[NV];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) q[v] = lds[off + (v * NTS + l) * SL];
-#pragma unroll
-                    for (int i = 0; i < NA; i++) a[i] = lds[off + AXO + (i * N + l) * SL];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) qb[v] += ops.w[l] * q[v];
-                    static_for<0, DIM>([&](auto dc) {
-                        constexpr int D = decltype(dc)::value;
-                        PDE::template flux<D>(q, a, F);
-#pragma unroll
-                        for (int v = 0; v < NV; v++) Fb[D][v] += ops.w[l] * F[v];
-                    });
-                }
-            } else {
-                double a[NA];
-                PDE::aux(ur[k], a);
-#pragma unroll
-                for (int v = 0; v < NV; v++) qb[v] = ur[k][v];
-                static_for<0, DIM>([&](auto dc) {
-                    constexpr int D = decltype(dc)::value;
-                    PDE::template flux<D>(ur[k], a, Fb[D]);
-                });
-            }
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
-#pragma unroll
-                for (int d = 0; d < DIM; d++) lds[off + ASZ + (v * NTS + 1 + d) * SL] = Fb[d][v];
-                lds[off + (v * NTS + 0) * SL] = ur[k][v];
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- volume integral + face extrapolation: pencil tasks (c, d, v, t), t fastest
-    for (int task = tid; task < CPB * DIM * NV * NF; task += NT) {
-        const int c = task / (DIM * NV * NF);
-        int r = task - c * (DIM * NV * NF);
-        const int d = r / (NV * NF);
-        r -= d * (NV * NF);
-        const int v = r / NF, t = r - v * NF;
-        const int ps = G::pstride(d);
-        const int off = c * CS + G::pbase(d, t) + v * NTS * SL;
-        double qb[N], Fb[N];
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            qb[j] = lds[off + ASZ + j * ps];
-            Fb[j] = lds[off + ASZ + (1 + d) * SL + j * ps];
-        }
-        const double sc = dt * idx[d];
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; j++) s += ops.Kxi[i * N + j] * Fb[j];
-            lds[off + (1 + d) * SL + i * ps] = sc * ops.iw[i] * s;
-        }
-        double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            qL += ops.phiL[j] * qb[j];
-            qR += ops.phiR[j] * qb[j];
-            FL += ops.phiL[j] * Fb[j];
-            FR += ops.phiR[j] * Fb[j];
-        }
-        const long cell = cell_of(c);
-        if (cell >= 0) {
-            double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
-            double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
-            tl[(0 * NV + v) * NF + t] = qL;
-            tl[(1 * NV + v) * NF + t] = FL;
-            tr[(0 * NV + v) * NF + t] = qR;
-            tr[(1 * NV + v) * NF + t] = FR;
-        }
-    }
-    __syncthreads();
-
-    // ---- u* = u + sum_d vol_d, written AoS (coalesced)
-    for (int task = tid; task < CPB * NN * NV; task += NT) {
-        const int c = task / (NN * NV), e = task - c * (NN * NV);
-        const int n = e / NV, v = e - n * NV;
-        const int off = c * CS + G::node_off(n) + v * NTS * SL;
-        double us = lds[off];
-#pragma unroll
-        for (int d = 0; d < DIM; d++) us += lds[off + (1 + d) * SL];
-        const long cell = cell_of(c);
-        if (cell >= 0) u_out[cell * (NN * NV) + e] = us;
-    }
-    __syncthreads();          // the slab is reused by the next cell
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Stage A, single-stage variant (n_picard = 0: qbar := u, Fbar := f(u); BASELINE configs[1])
 // ------------------------------------------------------------------------------------------
 // No space-time image: per cell only qbar and Fbar_d live in LDS ((1+DIM) node arrays per variable,

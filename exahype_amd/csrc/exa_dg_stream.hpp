@@ -22,6 +22,28 @@
 #pragma once
 #include "exa_dg_kernels.hpp"
 
+// Diagnostic ablations (never in the product build): -DEXA_ABL_SKIP_D / _LOAD / _FOLD / _SLAB drop a phase to time the rest.
+#ifdef EXA_ABL_SKIP_D
+#define EXA_ABL_COND_D && n_it < 0
+#else
+#define EXA_ABL_COND_D
+#endif
+#ifdef EXA_ABL_SKIP_LOAD
+#define EXA_ABL_COND_LOAD && n_it < 0
+#else
+#define EXA_ABL_COND_LOAD
+#endif
+#ifdef EXA_ABL_SKIP_FOLD
+#define EXA_ABL_COND_FOLD && n_it < 0
+#else
+#define EXA_ABL_COND_FOLD
+#endif
+#ifdef EXA_ABL_SKIP_SLAB
+#define EXA_ABL_COND_SLAB && n_it < 0
+#else
+#define EXA_ABL_COND_SLAB
+#endif
+
 namespace exa {
 
 // Opaque copies: values derived from them cannot be hoisted out of the step loop (the compiler otherwise
@@ -34,6 +56,7 @@ template <int N> struct StreamGeo {
     static constexpr int PY = (N % 2 == 0) ? N + 1 : N;      // row stride
     static constexpr int PX = N * PY;                         // plane stride
     static constexpr int SL = N * PX;                         // one (var, level) image
+    static constexpr bool PERMUTE = (N == 8);                 // see the owner permutation in the kernel
     __device__ static inline int node_off(int n) { return (n / NF) * PX + ((n / N) % N) * PY + n % N; }
     __device__ static constexpr int pstride(int d) { return d == 0 ? PX : (d == 1 ? PY : 1); }
     // first node of pencil t (t = lexicographic index of the remaining axes = face-node index of the traces)
@@ -90,9 +113,27 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
     const bool d_task = grp < DIM && d_r < TH;
     // owner role: node, half of the output levels; loader role: node, level slot (same split)
     const int o_h = __builtin_amdgcn_readfirstlane(tid / OWNH);
-    const int o_n = tid - o_h * OWNH;
-    const bool owner = o_h < 2 && o_n < NN;
-    const int o_off0 = G::node_off(o_n < NN ? o_n : 0);
+    const int o_slot = tid - o_h * OWNH;                                    // lane-linear: indexes the slab
+    const bool owner = o_h < 2 && o_slot < NN;
+    int o_n = o_slot < NN ? o_slot : 0;                                     // node of this owner
+    if constexpr (G::PERMUTE) {
+        // Owner slot -> node permutation that makes the node-linear LDS phases (load, fold, averages) conflict-free
+        // under the padded strides: in a block of 256 nodes (4 planes) every residue of node_off mod 32 occurs
+        // exactly 8 times, so the k-th node of residue r goes to lane r of the k-th 32-lane group -- ds_read_b64
+        // groups see 32 distinct double-banks, ds_write_b64 groups (16 lanes) 16 distinct ones.
+        int* table = reinterpret_cast<int*>(lds);
+        if (tid < NN) {
+            const int n = tid, blk = n & ~255;
+            const int r = G::node_off(n) & 31;
+            int rank = 0;
+            for (int m = blk; m < n; m++) rank += ((G::node_off(m) & 31) == r) ? 1 : 0;
+            table[blk + rank * 32 + r] = n;
+        }
+        __syncthreads();
+        o_n = table[o_slot < NN ? o_slot : 0];
+        __syncthreads();
+    }
+    const int o_off0 = G::node_off(o_n);
 
     // Start the workgroups of an XCD staggered over roughly one Picard iteration: they all do the same work, so
     // without it every CU writes its share of the slab in the same microsecond (31 MB chip-wide at N = 8) and the
@@ -118,7 +159,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
             for (int g = 0; g < ngroups; g++) {
                 const int nl = it == 0 ? 1 : (LH + g < N ? 2 : 1);
                 // ---- load: q of the level, flux scalars once per node
-                if (owner && o_h < nl) {
+                if (owner && o_h < nl EXA_ABL_COND_LOAD) {
                     double a[NA];
                     const int o_off = opaque_v(o_off0) + opaque_s(o_h) * SL;
                     PDE::aux_fast(nxt, a);
@@ -129,15 +170,15 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 }
                 if (owner) {                                     // fetch ahead: the next level of this lane, or u for the update
                     const int ln = opaque_s(o_h) * LH + g + 1;
-                    const int n = opaque_v(o_n);
                     if (g + 1 < ngroups) {
-                        if (ln < N) {
+                        if (ln < N EXA_ABL_COND_SLAB) {
+                            const int sl = opaque_v(o_slot);
                             const double* row = qs + (size_t)ln * NV * NN;       // uniform base + lane offset: saddr loads
 #pragma unroll
-                            for (int v = 0; v < NV; v++) nxt[v] = row[v * NN + n];
+                            for (int v = 0; v < NV; v++) nxt[v] = row[v * NN + sl];
                         }
                     } else {
-                        const double* un = u_in + (cell * NN + n) * NV;
+                        const double* un = u_in + (cell * NN + opaque_v(o_n)) * NV;
 #pragma unroll
                         for (int v = 0; v < NV; v++) nxt[v] = un[v];
                     }
@@ -151,7 +192,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 int hoff = 0;
                 static_for<0, DIM>([&](auto dc) {
                     constexpr int D = decltype(dc)::value;
-                    if (d_task && grp == D && d_ls < nl) {
+                    if (d_task && grp == D && d_ls < nl EXA_ABL_COND_D) {
                         constexpr int ps = G::pstride(D);
                         const int half = opaque_s(d_half);
                         const EXA_AS4 double* Dcol = ops_here<N>(ops_raw)->DT + half * HR;     // DT[j][half*HR + i]
@@ -205,7 +246,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 __syncthreads();
                 EXA_STAMP(5);
                 // ---- fold: acc[l'] += T[l'][l] * S_l for the levels of this step
-                if (owner) {
+                if (owner EXA_ABL_COND_FOLD) {
                     // T and Tsum are adjacent in DgOps: one scalar-indexed array serves both (a select between two
                     // pointers turns the coefficient into a serialised vector load)
                     const EXA_AS4 double* Tm = ops_here<N>(ops_raw)->T;
@@ -252,13 +293,13 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
             // from registers, the others wait in the slab
             if (owner) {
                 const int lp0 = opaque_s(o_h) * LH;
-                const int n = opaque_v(o_n);
+                const int n = opaque_v(o_slot);
                 const bool keep = it + 1 < n_it;
 #pragma unroll
                 for (int k = 0; k < LH; k++) {
 #pragma unroll
                     for (int v = 0; v < NV; v++) acc[k][v] = nxt[v] - dt * acc[k][v];
-                    if (k > 0 && keep && (N % 2 == 0 || k + 1 < LH || lp0 + k < N)) {
+                    if (k > 0 && keep EXA_ABL_COND_SLAB && (N % 2 == 0 || k + 1 < LH || lp0 + k < N)) {
                         double* row = qs + (size_t)(lp0 + k) * NV * NN;          // uniform base + lane offset: saddr stores
 #pragma unroll
                         for (int v = 0; v < NV; v++) row[v * NN + n] = acc[k][v];

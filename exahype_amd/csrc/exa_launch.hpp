@@ -13,7 +13,7 @@ struct DgOpsHost {
         K1[MAXN * MAXN];
     void* dev;     // DgOps<N> image in HBM (read by the kernels through the constant address space)
     void* lim;     // limiter tables in HBM: P[Ns][N] then R[N][Ns] (null until first use)
-    void* scratch; // per-workgroup cell-image slabs of the scratch variant (N whose image exceeds LDS), else null
+    void* scratch; // per-workgroup slabs of the level-streamed stage A (N whose cell image exceeds LDS), else null
 };
 // dg_operators_host.cpp: Gauss-Legendre nodes by Newton, barycentric derivative
 // matrix, K1 inverse by Gauss-Jordan, all in long double.
