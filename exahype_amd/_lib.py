@@ -39,6 +39,9 @@ SIGNATURES = {
     "exa_lim_operators": (C.c_int, [_vp, _vp, _vp]),
     "exa_lim_patch_count": (C.c_long, [_vp]),
     "exa_dg_project_patches": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, _vp]),
+    "exa_dg_project_patches_ghost": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, C.POINTER(_vp), _vp]),
+    "exa_lim_face_layer_count": (C.c_long, [_vp, C.c_int]),
+    "exa_lim_face_layers": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "exa_dg_reconstruct_patches": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, _vp]),
     "exa_dg_max_eigenvalue": (C.c_int, [_vp, _vp, _vp, _vp]),
     "exa_dg_step_periodic": (C.c_int, [_vp, _vp, _vp, C.c_double, _dp, C.c_int, _vp]),

@@ -408,14 +408,40 @@ static int lim_tables(exa_dg_plan* p) {
     return EXA_OK;
 }
 
-int exa_dg_project_patches(exa_dg_plan* p, const double* u_dev, const long* cells_dev, long n, double* patch_dev, void* stream) {
+int exa_dg_project_patches_ghost(exa_dg_plan* p, const double* u_dev, const long* cells_dev, long n, double* patch_dev,
+                                 const double* const* ghost_layers_dev, void* stream) {
     if (!p || !u_dev || (n > 0 && (!cells_dev || !patch_dev)) || n < 0) { set_error("exa_dg_project_patches: bad argument"); return EXA_ERR_INVALID; }
     int rc = use_device(p->device);
     if (rc) return rc;
     rc = lim_tables(p);
     if (rc) return rc;
     const int Ns = 2 * p->N - 1;
-    return limiter_project(p->dim, p->N, Ns, p->nv, p->nc, u_dev, cells_dev, n, patch_dev, static_cast<const double*>(p->ops.lim), (hipStream_t)stream);
+    LimGhosts gh{};
+    for (int f = 0; f < 6; f++) gh.layer[f] = (ghost_layers_dev && f < 2 * p->dim) ? ghost_layers_dev[f] : nullptr;
+    return limiter_project(p->dim, p->N, Ns, p->nv, p->nc, u_dev, cells_dev, n, patch_dev, static_cast<const double*>(p->ops.lim), &gh,
+                           (hipStream_t)stream);
+}
+
+int exa_dg_project_patches(exa_dg_plan* p, const double* u_dev, const long* cells_dev, long n, double* patch_dev, void* stream) {
+    return exa_dg_project_patches_ghost(p, u_dev, cells_dev, n, patch_dev, nullptr, stream);
+}
+
+long exa_lim_face_layer_count(const exa_dg_plan* p, int d) {
+    if (!p || d < 0 || d >= p->dim) return 0;
+    long nt = 1;
+    for (int b = 0; b < p->dim; b++)
+        if (b != d) nt *= p->nc[b];
+    return nt * lpow(2 * p->N - 1, p->dim - 1) * p->nv;
+}
+
+int exa_lim_face_layers(exa_dg_plan* p, const double* u_dev, int d, int side, const double* need_dev, double* out_dev, void* stream) {
+    if (!p || !u_dev || !out_dev || d < 0 || d >= p->dim || side < 0 || side > 1) { set_error("exa_lim_face_layers: bad argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    rc = lim_tables(p);
+    if (rc) return rc;
+    return limiter_face_layers(p->dim, p->N, 2 * p->N - 1, p->nv, p->nc, u_dev, d, side, need_dev, out_dev,
+                               static_cast<const double*>(p->ops.lim), (hipStream_t)stream);
 }
 
 int exa_dg_reconstruct_patches(exa_dg_plan* p, const double* patch_dev, const long* cells_dev, long n, double* u_dev, void* stream) {

@@ -20,8 +20,11 @@ struct DgOpsHost {
 int build_dg_operators(int N, DgOpsHost* out);
 int build_limiter_operators(const DgOpsHost* o, int Ns, double* P, double* R);     // P[Ns][N], R[N][Ns]
 // limiter.hip
+struct LimGhosts { const double* layer[6]; };   // [d*2+side]: neighbour block's subcell layer at that block face, or null
 int limiter_project(int dim, int N, int Ns, int nv, const long* nc, const double* u, const long* cells, long n, double* patch,
-                    const double* Pdev, hipStream_t s);
+                    const double* Pdev, const LimGhosts* ghosts, hipStream_t s);
+int limiter_face_layers(int dim, int N, int Ns, int nv, const long* nc, const double* u, int a, int side, const double* need,
+                        double* out, const double* Pdev, hipStream_t s);
 int limiter_reconstruct(int dim, int N, int Ns, int nv, const double* patch, const long* cells, long n, double* u,
                         const double* Rdev, hipStream_t s);
 

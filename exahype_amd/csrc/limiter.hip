@@ -33,7 +33,8 @@ __device__ inline void lim_apply(const double* __restrict__ M, int ldm, int r0, 
 template <int DIM>
 __global__ void __launch_bounds__(256)
 limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, const double* __restrict__ u,
-                       const long* __restrict__ cells, double* __restrict__ patch, const double* __restrict__ P) {
+                       const long* __restrict__ cells, double* __restrict__ patch, const double* __restrict__ P,
+                       LimGhosts gh) {
     __shared__ double A[LIM_MAX], B[LIM_MAX];
     const long cell = cells[blockIdx.x];
     const int S = Ns + 2;
@@ -71,6 +72,30 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
         // ---- face halos from the neighbours' projections (one subcell layer each)
         for (int a = 0; a < DIM; a++)
             for (int side = 0; side < 2; side++) {
+                const long layer = NsD / Ns;
+                const double* g = gh.layer[a * 2 + side];
+                if (g && cc[a] == (side ? nc[a] - 1 : 0)) {
+                    // block boundary of a sharded grid: the neighbour's adjacent subcell layer arrived by exchange,
+                    // layout [transverse cell][transverse subcell][var] (limiter_face_layers_kernel on the neighbour)
+                    long tc = 0;
+                    for (int b = 0; b < DIM; b++)
+                        if (b != a) tc = tc * nc[b] + cc[b];
+                    const double* gl = g + tc * layer * nv;
+                    for (int t = threadIdx.x; t < layer; t += blockDim.x) {
+                        int r = t, idx[3] = {0, 0, 0};
+                        for (int b = DIM - 1; b >= 0; b--) {
+                            if (b == a) continue;
+                            idx[b] = r % Ns + 1;
+                            r /= Ns;
+                        }
+                        idx[a] = side ? S - 1 : 0;
+                        long flat = 0;
+                        for (int b = 0; b < DIM; b++) flat = flat * S + idx[b];
+                        pt[flat * nv + v] = gl[(long)t * nv + v];
+                    }
+                    __syncthreads();
+                    continue;
+                }
                 long nb[3] = {cc[0], cc[1], cc[2]};
                 nb[a] = (nb[a] + (side ? 1 : nc[a] - 1)) % nc[a];
                 const long ncell = (nb[0] * nc1 + nb[1]) * (DIM == 3 ? nc2 : 1) + nb[2];
@@ -85,7 +110,6 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
                     __syncthreads();
                     double* tmp = s2; s2 = d2; d2 = tmp;
                 }
-                long layer = NsD / Ns;
                 for (int t = threadIdx.x; t < layer; t += blockDim.x) {
                     // t enumerates the transverse subcells (axes != a, lexicographic)
                     int r = t, idx[3] = {0, 0, 0};
@@ -101,6 +125,41 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
                 }
                 __syncthreads();
             }
+    }
+}
+
+// Sharded grids: the subcell layer next to the block face (a, side) of every cell of the block's boundary layer whose
+// neighbour across the face is troubled (need[t] != 0; need == nullptr: all) -- what that neighbour's patch needs as
+// halo.  out[transverse cell][transverse subcell][var]; one workgroup per transverse cell.
+template <int DIM>
+__global__ void __launch_bounds__(256)
+limiter_face_layers_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, const double* __restrict__ u, int a, int side,
+                           const double* __restrict__ need, double* __restrict__ out, const double* __restrict__ P) {
+    __shared__ double A[LIM_MAX], B[LIM_MAX];
+    const long tc = blockIdx.x;
+    if (need && need[tc] == 0.0) return;
+    const long nc[3] = {nc0, nc1, nc2};
+    long NN = 1, NsD = 1;
+    for (int b = 0; b < DIM; b++) { NN *= N; NsD *= Ns; }
+    const long layer = NsD / Ns;
+    long cc[3] = {0, 0, 0};
+    { long r = tc; for (int b = DIM - 1; b >= 0; b--) { if (b == a) continue; cc[b] = r % nc[b]; r /= nc[b]; } }
+    cc[a] = side ? nc[a] - 1 : 0;
+    const long cell = (cc[0] * nc1 + cc[1]) * (DIM == 3 ? nc2 : 1) + cc[2];
+    for (int v = 0; v < nv; v++) {
+        for (int t = threadIdx.x; t < NN; t += blockDim.x) A[t] = u[(cell * NN + t) * nv + v];
+        __syncthreads();
+        int e[3] = {N, N, N};
+        double *src = A, *dst = B;
+        for (int b = 0; b < DIM; b++) {
+            if (b == a) lim_apply(P, N, side ? Ns - 1 : 0, 1, N, src, dst, DIM, e, b);     // the layer at the face only
+            else lim_apply(P, N, 0, Ns, N, src, dst, DIM, e, b);
+            e[b] = (b == a) ? 1 : Ns;
+            __syncthreads();
+            double* tmp = src; src = dst; dst = tmp;
+        }
+        for (int t = threadIdx.x; t < layer; t += blockDim.x) out[(tc * layer + t) * nv + v] = src[t];
+        __syncthreads();
     }
 }
 
@@ -136,12 +195,27 @@ limiter_reconstruct_kernel(int N, int Ns, int nv, const double* __restrict__ pat
 }
 
 int limiter_project(int dim, int N, int Ns, int nv, const long* nc, const double* u, const long* cells, long n, double* patch,
-                    const double* Pdev, hipStream_t s) {
+                    const double* Pdev, const LimGhosts* ghosts, hipStream_t s) {
     if (n <= 0) return 0;
-    if (dim == 2) hipLaunchKernelGGL((limiter_project_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, cells, patch, Pdev);
-    else hipLaunchKernelGGL((limiter_project_kernel<3>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, cells, patch, Pdev);
+    LimGhosts gh{};
+    if (ghosts) gh = *ghosts;
+    if (dim == 2) hipLaunchKernelGGL((limiter_project_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, cells, patch, Pdev, gh);
+    else hipLaunchKernelGGL((limiter_project_kernel<3>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, cells, patch, Pdev, gh);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("limiter_project launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+int limiter_face_layers(int dim, int N, int Ns, int nv, const long* nc, const double* u, int a, int side, const double* need,
+                        double* out, const double* Pdev, hipStream_t s) {
+    long nt = 1;
+    for (int b = 0; b < dim; b++)
+        if (b != a) nt *= nc[b];
+    if (nt <= 0) return 0;
+    if (dim == 2) hipLaunchKernelGGL((limiter_face_layers_kernel<2>), dim3((unsigned)nt), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, a, side, need, out, Pdev);
+    else hipLaunchKernelGGL((limiter_face_layers_kernel<3>), dim3((unsigned)nt), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, a, side, need, out, Pdev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("limiter_face_layers launch: %s", hipGetErrorString(e)); return -2; }
     return 0;
 }
 

@@ -432,18 +432,25 @@ AderDgSolver.run = _dg_run
 # FV subcell limiter (BASELINE configs[4])
 # ----------------------------------------------------------------------------------------------
 class SubcellLimiter:
-    """Limited ADER-DG step on one periodic block: untroubled cells take the DG step, troubled cells the FV
-    Rusanov patch update (patch_size 2p+1, halo 1 -- the reference's kernel shape) of their projected data.
-    The troubled mask is an input (synthetic Bernoulli mask in the benchmark; a physical detector is host logic
-    outside this path)."""
+    """Limited ADER-DG step: untroubled cells take the DG step, troubled cells the FV Rusanov patch update
+    (patch_size 2p+1, halo 1 -- the reference's kernel shape) of their projected data.  The troubled mask is an
+    input (synthetic Bernoulli mask in the benchmark; a physical detector is host logic outside this path).
+
+    On a sharded grid (solver.part) two small exchanges precede the projection: the troubled flags of the blocks'
+    boundary layers, then -- only where the cell across the face is troubled -- the adjacent subcell layer of the
+    boundary cells; the patches of troubled cells at a block face take their halo from those."""
 
     def __init__(self, solver):
-        if solver.halo is not None:
-            raise NotImplementedError("the limiter runs on a single periodic block this round (no subcell halo exchange yet)")
         self.s = solver
         self.Ns = 2 * solver.N - 1
         self.patch_doubles = solver.lib.exa_lim_patch_count(solver._plan)
         self._fv = {}
+        self.hx_mask = self.hx_layer = None
+        if solver.halo is not None:
+            stage = solver.halo.stage
+            self.hx_mask = HaloExchange(solver.part, solver.nc, 1, solver.dev, stage_through_host=stage)
+            self.hx_layer = HaloExchange(solver.part, solver.nc, self.Ns ** (solver.dim - 1) * solver.nv, solver.dev,
+                                         stage_through_host=stage)
 
     def operators(self):
         N, Ns = self.s.N, self.Ns
@@ -451,15 +458,41 @@ class SubcellLimiter:
         check(self.s.lib.exa_lim_operators(self.s._plan, P.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p)))
         return P, R
 
+    def _exchange_subcell_layers(self, m):
+        """m: troubled flags of the block, float64 [nc0, nc1, nc2] on the device.  Returns the ghost-layer pointer array."""
+        s, hm, hl = self.s, self.hx_mask, self.hx_layer
+        nc3 = s.nc + [1] * (3 - s.dim)
+        for d in range(s.dim):
+            if s.part.partitioned(d):
+                hm.send[d * 2 + 0].copy_(m.select(d, 0).reshape(-1, 1))
+                hm.send[d * 2 + 1].copy_(m.select(d, nc3[d] - 1).reshape(-1, 1))
+        hm.start()
+        hm.finish()
+        for d in range(s.dim):
+            if not s.part.partitioned(d):
+                continue
+            for side in range(2):
+                # ghost[d*2+side] = flags of the cells across my face (d, side): where set, they need my layer
+                check(s.lib.exa_lim_face_layers(s._plan, C.c_void_p(s.u.data_ptr()), d, side,
+                                                C.c_void_p(hm.ghost[d * 2 + side].data_ptr()),
+                                                C.c_void_p(hl.send[d * 2 + side].data_ptr()), _stream_ptr()))
+        hl.start()
+        hl.finish()
+        return hl.ghost_ptrs()
+
     def step(self, dt, mask):
         torch = _torch()
         s = self.s
-        m = torch.as_tensor(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask)).to(s.dev).reshape(-1)
-        cells = torch.nonzero(m, as_tuple=False).reshape(-1).to(torch.int64).contiguous()
+        m = torch.as_tensor(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask)).to(s.dev)
+        cells = torch.nonzero(m.reshape(-1), as_tuple=False).reshape(-1).to(torch.int64).contiguous()
         n = int(cells.numel())
+        ghosts = None
+        if self.hx_layer is not None:                          # every rank takes part, troubled cells or not
+            nc3 = s.nc + [1] * (3 - s.dim)
+            ghosts = self._exchange_subcell_layers(m.to(torch.float64).reshape(nc3))
         patches = torch.empty((max(n, 1), self.patch_doubles), dtype=torch.float64, device=s.dev)
-        check(s.lib.exa_dg_project_patches(s._plan, C.c_void_p(s.u.data_ptr()), C.c_void_p(cells.data_ptr()), n,
-                                           C.c_void_p(patches.data_ptr()), _stream_ptr()))
+        check(s.lib.exa_dg_project_patches_ghost(s._plan, C.c_void_p(s.u.data_ptr()), C.c_void_p(cells.data_ptr()), n,
+                                                 C.c_void_p(patches.data_ptr()), ghosts, _stream_ptr()))
         s.step(dt)                                             # candidate DG solution everywhere
         if n == 0:
             return 0

@@ -145,6 +145,17 @@ int exa_dg_project_patches(exa_dg_plan* plan, const double* u_dev, const long* c
                            void* stream);
 int exa_dg_reconstruct_patches(exa_dg_plan* plan, const double* patch_dev, const long* cells_dev, long n, double* u_dev,
                                void* stream);
+/* Sharded grids ("a second exchange of one subcell halo layer for troubled boundary cells").
+ * exa_lim_face_layers: for the cells of the block's boundary layer at face (d, side) write the projected subcell
+ * layer adjacent to that face, out_dev[transverse cell][N_s^(dim-1)][n_vars] (exa_lim_face_layer_count(plan, d)
+ * doubles); need_dev[transverse cell] != 0 selects the cells whose neighbour across the face is troubled (NULL: all;
+ * skipped entries are left untouched).  The neighbour passes the received buffer as ghost_layers_dev[d*2+side'] of
+ * its own face (side' = 1-side) to exa_dg_project_patches_ghost; NULL entries keep the periodic wrap in the block. */
+long exa_lim_face_layer_count(const exa_dg_plan* plan, int d);
+int exa_lim_face_layers(exa_dg_plan* plan, const double* u_dev, int d, int side, const double* need_dev, double* out_dev,
+                        void* stream);
+int exa_dg_project_patches_ghost(exa_dg_plan* plan, const double* u_dev, const long* cells_dev, long n, double* patch_dev,
+                                 const double* const* ghost_layers_dev, void* stream);
 /* max over all cells/nodes/directions of maxEigenvalue (for a CFL time step);
  * result is written to *lambda_dev (one double, device). */
 int exa_dg_max_eigenvalue(exa_dg_plan* plan, const double* u_dev, double* lambda_dev, void* stream);

@@ -59,3 +59,62 @@ def test_sharded_step_equals_global_oracle(tmp_path, N, nc, pdims):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+
+
+LIM_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from exahype_amd import solvers as exa
+import oracle
+from oracle import aderdg_numpy as A
+from oracle.dg_operators import operators
+from oracle.limiter_numpy import limited_step
+from tests.util import euler_dg_state
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dim, N, nc = %(dim)d, %(N)d, %(nc)r
+pdims = %(pdims)r
+part = exa.CartesianPartition(world, rank, dim, pdims)
+G = tuple(nc[a] * part.pdims[a] for a in range(dim))
+u = euler_dg_state(G + (N,) * dim, seed=7)
+dx = [1.0 / G[0]] * dim
+dt = 0.02 * dx[0] / (2 * N - 1)
+mask = np.random.default_rng(11).random(G) < 0.4
+mask[(0,) * dim] = True                                          # a troubled cell in the corner: every face is a block or wrap face
+s = exa.AderDgSolver(dim, N, nc, dx=dx, part=part, backend_is_gloo=True)
+lim = exa.SubcellLimiter(s)
+sl = tuple(slice(part.coords[a] * nc[a], (part.coords[a] + 1) * nc[a]) for a in range(dim))
+s.upload(u[sl])
+ops = operators(N)
+def fv(patch, dt, h):
+    return oracle.fv_corrected(patch[None], dt, h, dim, patch.shape[0] - 2, 1, 5, 0, 1, oracle.PDE_EULER)[0]
+ref = u.copy()
+for _ in range(2):
+    n = lim.step(dt, mask[sl])
+    assert n == int(mask[sl].sum())
+    ref = limited_step(ref, mask, dt, dx, ops, A.Euler(), fv)
+torch.cuda.synchronize()
+got, want = s.download(), ref[sl]
+err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+assert err < 1e-10, err
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "rel err", err)
+'''
+
+
+@pytest.mark.parametrize("dim,N,nc,pdims", [(2, 3, (2, 3), [2, 1]), (3, 3, (2, 2, 1), [1, 2, 1]), (2, 4, (3, 1), [1, 2])])
+def test_sharded_limited_step_equals_global_oracle(tmp_path, dim, N, nc, pdims):
+    """cfg 4 across ranks: troubled cells at a block face take their FV halo from the neighbour block's subcell layer."""
+    world = 2
+    script = tmp_path / "worker.py"
+    script.write_text(LIM_WORKER % dict(root=ROOT, dim=dim, N=N, nc=nc, pdims=pdims))
+    port = 31500 + (os.getpid() + N * 13 + nc[0] + dim) % 2000
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
