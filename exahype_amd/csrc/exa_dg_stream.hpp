@@ -66,36 +66,43 @@ template <int N> struct StreamGeo {
     }
 };
 
-template <int N, class PDE> struct StageAStream {
+// HS = tasks per pencil in the derive phase (2: row halves, 40 VGPRs of partial sums; 1: whole pencils, 80),
+// OH = owners per node in the load / fold phases (2: each owns half of the output levels; 1: all of them).
+// HS = OH = 2 runs 16 waves at <= 128 VGPRs, HS = OH = 1 runs 8 waves at <= 256 VGPRs and reads each pencil once.
+template <int N, class PDE, int HS, int OH> struct StageAStream {
     using G = StreamGeo<N>;
     static constexpr int NV = PDE::NV, NA = PDE::NAUX;
-    static constexpr int LG = 2;                              // time levels per step
-    static constexpr int HR = (N + 1) / 2;                    // rows of a half task
-    static constexpr int LH = (N + 1) / 2;                    // output levels of a node owner
+    static constexpr int LG = 2;                              // time levels (slots) per step
+    static constexpr int LS = (N + 1) / 2;                    // steps per iteration; slot ls of step g holds level ls*LS + g
+    static constexpr int HR = (N + HS - 1) / HS;              // rows of a derive task
+    static constexpr int LH = OH == 2 ? LS : N;               // output levels of a node owner
+    static constexpr int SLOTS = LG / OH;                     // level slots a loader lane serves
     static constexpr int QSZ = NV * LG * G::SL;               // Q, A, B
-    static constexpr int AXO = 3 * QSZ;                       // flux scalars [a][level][node]
+    static constexpr int AXO = 3 * QSZ;                       // flux scalars [a][slot][node]
     static constexpr int PIC_D = 3 * QSZ + NA * LG * G::SL;   // Picard phases
     static constexpr int FIN_D = 4 * NV * G::SL;              // final phases: qbar, Fbar_x, Fbar_y, Fbar_z
     static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(PIC_D > FIN_D ? PIC_D : FIN_D);
     static constexpr int TH = LG * G::NF;                     // pencils per direction and step
-    static constexpr int HW = ((TH + 63) / 64) * 64;          // lanes of one half of a direction group (wave-aligned)
-    static constexpr int GW = 2 * HW;                         // lanes of a direction group: two half tasks per pencil
-    static constexpr int OWNH = ((G::NN + 63) / 64) * 64;     // lanes of an owner half (wave-aligned)
-    static constexpr int NT = (3 * GW > 2 * OWNH) ? 3 * GW : 2 * OWNH;
+    static constexpr int HW = ((TH + 63) / 64) * 64;          // lanes of one task part of a direction group (wave-aligned)
+    static constexpr int GW = HS * HW;                        // lanes of a direction group
+    static constexpr int OWNH = ((G::NN + 63) / 64) * 64;     // lanes of an owner part (wave-aligned)
+    static constexpr int NT = (3 * GW > OH * OWNH) ? 3 * GW : OH * OWNH;
     static constexpr int SKEW_SLEEP = 32;                     // x 64 cycles x 32 slots ~ one iteration
-    static constexpr size_t SLAB_D = (size_t)NV * N * G::NN;  // doubles of slab per workgroup: q[level][var][node]
+    static constexpr size_t SLAB_D = (size_t)NV * N * G::NN;  // doubles of slab per workgroup: q[level][var][owner slot]
+    static_assert(HS == 1 || HS == 2, "HS");
+    static_assert(OH == 1 || OH == 2, "OH");
 };
 
-template <int N, class PDE>
-__global__ void __launch_bounds__((StageAStream<N, PDE>::NT))
+template <int N, class PDE, int HS, int OH>
+__global__ void __launch_bounds__((StageAStream<N, PDE, HS, OH>::NT))
 dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
                          long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
                          const void* __restrict__ ops_raw, double* __restrict__ slab) {
     using G = StreamGeo<N>;
-    using SA = StageAStream<N, PDE>;
+    using SA = StageAStream<N, PDE, HS, OH>;
     constexpr int NV = PDE::NV, NA = PDE::NAUX, DIM = 3;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL;
-    constexpr int LG = SA::LG, HR = SA::HR, LH = SA::LH, QSZ = SA::QSZ, AXO = SA::AXO;
+    constexpr int LG = SA::LG, LS = SA::LS, HR = SA::HR, LH = SA::LH, SLOTS = SA::SLOTS, QSZ = SA::QSZ, AXO = SA::AXO;
     constexpr int NT = SA::NT, TH = SA::TH, HW = SA::HW, GW = SA::GW, OWNH = SA::OWNH;
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
@@ -104,17 +111,17 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
     const double idx[3] = {idx0, idx1, idx2};
     double* qs = slab + (size_t)blockIdx.x * SA::SLAB_D;
 
-    // derivative role: direction group, half task (half, level slot, pencil)
+    // derive role: direction group, task part (rows of D), level slot, pencil
     const int grp = __builtin_amdgcn_readfirstlane(tid / GW);
     const int bt = tid - grp * GW;
     const int d_half = __builtin_amdgcn_readfirstlane(bt / HW);             // wave-uniform: selects the rows of D
     const int d_r = bt - d_half * HW;
     const int d_ls = d_r / NF, d_t = d_r - d_ls * NF;
     const bool d_task = grp < DIM && d_r < TH;
-    // owner role: node, half of the output levels; loader role: node, level slot (same split)
+    // owner role: node x part of the output levels; loader role: node x level slot(s) (same split)
     const int o_h = __builtin_amdgcn_readfirstlane(tid / OWNH);
     const int o_slot = tid - o_h * OWNH;                                    // lane-linear: indexes the slab
-    const bool owner = o_h < 2 && o_slot < NN;
+    const bool owner = o_h < OH && o_slot < NN;
     int o_n = o_slot < NN ? o_slot : 0;                                     // node of this owner
     if constexpr (G::PERMUTE) {
         // Owner slot -> node permutation that makes the node-linear LDS phases (load, fold, averages) conflict-free
@@ -134,59 +141,70 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
         __syncthreads();
     }
     const int o_off0 = G::node_off(o_n);
+    // level of owned accumulator k:  OH == 2: o_h*LS + k (slot o_h, step k);  OH == 1: k (slot k / LS, step k % LS)
 
     // Start the workgroups of an XCD staggered over roughly one Picard iteration: they all do the same work, so
-    // without it every CU writes its share of the slab in the same microsecond (31 MB chip-wide at N = 8) and the
-    // bursts, not the average (~2 TB/s), set the pace.  Costs one iteration's time once per launch.
+    // without it every CU writes its share of the slab in the same microsecond (31 MB chip-wide at N = 8).
     for (int k = (blockIdx.x >> 3) & 31; k > 0; k--) __builtin_amdgcn_s_sleep(SA::SKEW_SLEEP);
 
     for (long b = blockIdx.x; b < box.nbox; b += gridDim.x) {
         const long cell = box.cell(b);
         double acc[LH][NV];                                      // time-update accumulators, then the final iterate
-        double nxt[NV];                                          // what the next load phase needs, fetched a step ahead
+        double nxt[SLOTS][NV];                                   // what the next load phase needs, fetched a step ahead
 #pragma unroll
         for (int k = 0; k < LH; k++)
 #pragma unroll
             for (int v = 0; v < NV; v++) acc[k][v] = 0.0;
 #pragma unroll
-        for (int v = 0; v < NV; v++) nxt[v] = owner ? u_in[(cell * NN + o_n) * NV + v] : 1.0;
+        for (int si = 0; si < SLOTS; si++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) nxt[si][v] = (owner && si == 0) ? u_in[(cell * NN + o_n) * NV + v] : 1.0;
 
         for (int it = 0; it < n_it; it++) {
             // iteration 0: the iterate is constant in time -- one level, row sums of T.  Later iterations: step g
-            // takes the levels g and LH + g, i.e. the level with index g of either owner half -- every lane loads
-            // what it wrote itself (no fence), a step ahead of its use (the slab latency hides under a whole step).
-            const int ngroups = it == 0 ? 1 : LH;
+            // takes the levels g and LS + g, so that every lane loads what it wrote itself (no fence), a step ahead
+            // of its use (the slab latency hides under a whole step).
+            const int ngroups = it == 0 ? 1 : LS;
             for (int g = 0; g < ngroups; g++) {
-                const int nl = it == 0 ? 1 : (LH + g < N ? 2 : 1);
-                // ---- load: q of the level, flux scalars once per node
-                if (owner && o_h < nl EXA_ABL_COND_LOAD) {
-                    double a[NA];
-                    const int o_off = opaque_v(o_off0) + opaque_s(o_h) * SL;
-                    PDE::aux_fast(nxt, a);
+                const int nl = it == 0 ? 1 : (LS + g < N ? 2 : 1);
+                // ---- load: q of the level(s), flux scalars once per node; then fetch ahead
+                if (owner) {
+                    const int base = opaque_v(o_off0);
 #pragma unroll
-                    for (int v = 0; v < NV; v++) lds[v * LG * SL + o_off] = nxt[v];
+                    for (int si = 0; si < SLOTS; si++) {
+                        const int ls = OH == 2 ? opaque_s(o_h) : si;
+                        if (ls < nl EXA_ABL_COND_LOAD) {
+                            double a[NA];
+                            const int o_off = base + ls * SL;
+                            PDE::aux_fast(nxt[si], a);
 #pragma unroll
-                    for (int k = 0; k < NA; k++) lds[AXO + k * LG * SL + o_off] = a[k];
-                }
-                if (owner) {                                     // fetch ahead: the next level of this lane, or u for the update
-                    const int ln = opaque_s(o_h) * LH + g + 1;
-                    if (g + 1 < ngroups) {
-                        if (ln < N EXA_ABL_COND_SLAB) {
-                            const int sl = opaque_v(o_slot);
-                            const double* row = qs + (size_t)ln * NV * NN;       // uniform base + lane offset: saddr loads
+                            for (int v = 0; v < NV; v++) lds[v * LG * SL + o_off] = nxt[si][v];
 #pragma unroll
-                            for (int v = 0; v < NV; v++) nxt[v] = row[v * NN + sl];
+                            for (int k = 0; k < NA; k++) lds[AXO + k * LG * SL + o_off] = a[k];
                         }
-                    } else {
+                    }
+                    if (g + 1 < ngroups) {                       // the next level of each slot, from the slab
+                        const int sl = opaque_v(o_slot);
+#pragma unroll
+                        for (int si = 0; si < SLOTS; si++) {
+                            const int ls = OH == 2 ? opaque_s(o_h) : si;
+                            const int ln = ls * LS + g + 1;
+                            if (ln < N EXA_ABL_COND_SLAB) {
+                                const double* row = qs + (size_t)ln * NV * NN;   // uniform base + lane offset: saddr loads
+#pragma unroll
+                                for (int v = 0; v < NV; v++) nxt[si][v] = row[v * NN + sl];
+                            }
+                        }
+                    } else {                                     // last step: u for the update
                         const double* un = u_in + (cell * NN + opaque_v(o_n)) * NV;
 #pragma unroll
-                        for (int v = 0; v < NV; v++) nxt[v] = un[v];
+                        for (int v = 0; v < NV; v++) nxt[0][v] = un[v];
                     }
                 }
                 EXA_STAMP(0);
                 __syncthreads();
                 EXA_STAMP(1);
-                // ---- derive: half task = rows [half*HR, half*HR + HR) of one pencil, all variables
+                // ---- derive: task = rows [half*HR, half*HR + HR) of one pencil, all variables
                 double s[HR][NV];
                 bool hold = false;
                 int hoff = 0;
@@ -194,10 +212,10 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                     constexpr int D = decltype(dc)::value;
                     if (d_task && grp == D && d_ls < nl EXA_ABL_COND_D) {
                         constexpr int ps = G::pstride(D);
-                        const int half = opaque_s(d_half);
+                        const int half = HS == 1 ? 0 : opaque_s(d_half);
                         const EXA_AS4 double* Dcol = ops_here<N>(ops_raw)->DT + half * HR;     // DT[j][half*HR + i]
                         const int off = opaque_v(d_ls * SL + G::pbase(D, d_t));
-                        const int soff = off + half * (HR * ps);                               // first row of this half
+                        const int soff = off + half * (HR * ps);                               // first row of this task
 #pragma unroll
                         for (int i = 0; i < HR; i++)
 #pragma unroll
@@ -220,7 +238,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         if constexpr (D > 0) {
 #pragma unroll
                             for (int i = 0; i < HR; i++)
-                                if (N % 2 == 0 || i + 1 < HR || half == 0) {                   // odd N: the second half has one row less
+                                if (HS * HR == N || i + 1 < HR || half == 0) {                 // odd N: the second half has one row less
 #pragma unroll
                                     for (int v = 0; v < NV; v++) lds[D * QSZ + soff + v * LG * SL + i * ps] = s[i][v];
                                 }
@@ -237,7 +255,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                     constexpr int ps = G::pstride(0);
 #pragma unroll
                     for (int i = 0; i < HR; i++)
-                        if (N % 2 == 0 || i + 1 < HR || d_half == 0) {
+                        if (HS * HR == N || i + 1 < HR || d_half == 0) {
 #pragma unroll
                             for (int v = 0; v < NV; v++) lds[hoff + v * LG * SL + i * ps] = s[i][v];
                         }
@@ -250,7 +268,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                     // T and Tsum are adjacent in DgOps: one scalar-indexed array serves both (a select between two
                     // pointers turns the coefficient into a serialised vector load)
                     const EXA_AS4 double* Tm = ops_here<N>(ops_raw)->T;
-                    const int lp0 = opaque_s(o_h) * LH;
+                    const int lp0 = OH == 2 ? opaque_s(o_h) * LS : 0;
                     const int o_off = opaque_v(o_off0);
                     if (g == 0) {
 #pragma unroll
@@ -261,11 +279,11 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
 #pragma unroll
                     for (int ls = 0; ls < LG; ls++) {
                         if (ls < nl) {
-                            const int l = ls * LH + g;
+                            const int l = ls * LS + g;
                             double S[NV], tl[LH];
 #pragma unroll
                             for (int k = 0; k < LH; k++) {
-                                const int lp = (N % 2 == 0 || k + 1 < LH || lp0 + k < N) ? lp0 + k : 0;
+                                const int lp = (LH * OH == N || k + 1 < LH || lp0 + k < N) ? lp0 + k : 0;
                                 tl[k] = Tm[__builtin_amdgcn_readfirstlane(it == 0 ? N * N + lp : lp * N + l)];
                             }
                             double Sx[NV], Sy[NV], Sz[NV];
@@ -289,34 +307,38 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 __syncthreads();
                 EXA_STAMP(7);
             }
-            // ---- new iterate q_l' = u - dt * acc (u arrived in nxt); level 0 of this lane feeds the next load phase
-            // from registers, the others wait in the slab
+            // ---- new iterate q_l' = u - dt * acc (u arrived in nxt[0]); the first level of each slot feeds the next
+            // load phase from registers, the others wait in the slab
             if (owner) {
-                const int lp0 = opaque_s(o_h) * LH;
+                const int lp0 = OH == 2 ? opaque_s(o_h) * LS : 0;
                 const int n = opaque_v(o_slot);
                 const bool keep = it + 1 < n_it;
 #pragma unroll
                 for (int k = 0; k < LH; k++) {
 #pragma unroll
-                    for (int v = 0; v < NV; v++) acc[k][v] = nxt[v] - dt * acc[k][v];
-                    if (k > 0 && keep EXA_ABL_COND_SLAB && (N % 2 == 0 || k + 1 < LH || lp0 + k < N)) {
+                    for (int v = 0; v < NV; v++) acc[k][v] = nxt[0][v] - dt * acc[k][v];
+                    const bool first = OH == 2 ? k == 0 : (k == 0 || k == LS);
+                    if (!first && keep EXA_ABL_COND_SLAB && (LH * OH == N || k + 1 < LH || lp0 + k < N)) {
                         double* row = qs + (size_t)(lp0 + k) * NV * NN;          // uniform base + lane offset: saddr stores
 #pragma unroll
                         for (int v = 0; v < NV; v++) row[v * NN + n] = acc[k][v];
                     }
                 }
 #pragma unroll
-                for (int v = 0; v < NV; v++) nxt[v] = acc[0][v];
+                for (int si = 0; si < SLOTS; si++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) nxt[si][v] = acc[OH == 2 ? 0 : si * LS][v];
             }
             EXA_STAMP(8);
         }
 
-        // ---- time averages: each owner over its levels, the two halves meet in LDS (qbar | Fbar_d)
+        // ---- time averages: each owner over its levels (OH == 2: the two parts meet in LDS): qbar | Fbar_d
         {
             double qb[NV], Fb[DIM][NV];
             const int o_off = opaque_v(o_off0);
             if (owner) {
                 const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
+                const int lp0 = OH == 2 ? o_h * LS : 0;
 #pragma unroll
                 for (int v = 0; v < NV; v++) qb[v] = 0.0;
 #pragma unroll
@@ -326,7 +348,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 if (n_it > 0) {
 #pragma unroll
                     for (int k = 0; k < LH; k++) {
-                        const int lp = o_h * LH + k;
+                        const int lp = lp0 + k;
                         if (lp < N) {
                             double a[NA], F[NV];
                             PDE::aux_fast(acc[k], a);
@@ -342,18 +364,16 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         }
                     }
                 } else if (o_h == 0) {                           // single stage: qbar = u, Fbar = F(u)
-                    double un[NV], a[NA];
+                    double a[NA];
+                    PDE::aux_fast(nxt[0], a);
 #pragma unroll
-                    for (int v = 0; v < NV; v++) un[v] = u_in[(cell * NN + o_n) * NV + v];
-                    PDE::aux_fast(un, a);
-#pragma unroll
-                    for (int v = 0; v < NV; v++) qb[v] = un[v];
+                    for (int v = 0; v < NV; v++) qb[v] = nxt[0][v];
                     static_for<0, DIM>([&](auto dc) {
                         constexpr int D = decltype(dc)::value;
-                        PDE::template flux<D>(un, a, Fb[D]);
+                        PDE::template flux<D>(nxt[0], a, Fb[D]);
                     });
                 }
-                if (o_h == 1) {
+                if (o_h == OH - 1) {
 #pragma unroll
                     for (int v = 0; v < NV; v++) {
                         lds[v * SL + o_off] = qb[v];
@@ -363,15 +383,17 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 }
             }
             __syncthreads();
-            if (owner && o_h == 0) {
+            if constexpr (OH == 2) {
+                if (owner && o_h == 0) {
 #pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    lds[v * SL + o_off] += qb[v];
+                    for (int v = 0; v < NV; v++) {
+                        lds[v * SL + o_off] += qb[v];
 #pragma unroll
-                    for (int d = 0; d < DIM; d++) lds[((1 + d) * NV + v) * SL + o_off] += Fb[d][v];
+                        for (int d = 0; d < DIM; d++) lds[((1 + d) * NV + v) * SL + o_off] += Fb[d][v];
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
         EXA_STAMP(9);
 

@@ -7,9 +7,13 @@ using namespace exa;
 #ifndef SN
 #define SN 8
 #endif
+#ifndef SHS
+#define SHS 2
+#define SOH 2
+#endif
 int main() {
     constexpr int N = SN;
-    using SA = StageAStream<N, Euler>;
+    using SA = StageAStream<N, Euler, SHS, SOH>;
     const long nc = 20, ncells = nc * nc * nc, NN = N * N * N;
     const long ndof = ncells * NN * 5, ntr = 3 * 2 * ncells * 2 * 5 * N * N;
     std::vector<double> h(ndof);
@@ -21,7 +25,7 @@ int main() {
     DgOps<N> o{};
     for (int i = 0; i < N; i++) { o.w[i] = 1.0 / N; o.iw[i] = N; o.phiL[i] = 0.1; o.phiR[i] = 0.1; o.Tsum[i] = 0.06; for (int j = 0; j < N; j++) { o.D[i*N+j] = 0.01*(i-j); o.DT[j*N+i] = 0.01*(i-j); o.Kxi[i*N+j] = 0.01; o.T[i*N+j] = 0.01; } }
     hipMemcpy(ops, &o, sizeof(o), hipMemcpyHostToDevice);
-    auto kern = dg_stage_a_stream_kernel<N, Euler>;
+    auto kern = dg_stage_a_stream_kernel<N, Euler, SHS, SOH>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SA::LDS_BYTES);
     CellBox box; for (int d = 0; d < 3; d++) { box.nc[d] = nc; box.lo[d] = 0; box.nb[d] = nc; } box.nbox = ncells;
     for (int rep = 0; rep < 2; rep++) {
@@ -40,7 +44,7 @@ int main() {
 #endif
         const char* names[12] = {"load", "load barrier", "D work", "D barrier", "x store", "x barrier", "fold", "fold barrier", "new q + fence", "averages (F1)", "vol+traces (F2)", "store (F3)"};
         if (rep == 0) continue;
-        printf("N=%d, %ld cells, %.2f ms; cycles per cell, first wave of each 256-lane group (x, y, z, owners-only):\n", N, ncells, ms);
+        printf("N=%d HS=%d OH=%d, %ld cells, %.2f ms; cycles per cell, first wave of each 256-lane group (x, y, z, owners-only):\n", N, SHS, SOH, ncells, ms);
         for (int k = 0; k < 12; k++) printf("   %-18s %9.0f %9.0f %9.0f %9.0f\n", names[k], (double)z[k] / ncells, (double)z[12 + k] / ncells, (double)z[24 + k] / ncells, (double)z[36 + k] / ncells);
         double tot = 0; for (int k = 0; k < 12; k++) tot += z[k];
         printf("   total              %9.0f\n", tot / ncells);
