@@ -44,6 +44,8 @@ SIGNATURES = {
     "exa_lim_face_layers": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "exa_dg_reconstruct_patches": (C.c_int, [_vp, _vp, _vp, C.c_long, _vp, _vp]),
     "exa_dg_max_eigenvalue": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "exa_dg_has_fused_step": (C.c_int, [_vp]),
+    "exa_dg_step_fused": (C.c_int, [_vp, _vp, _vp, C.c_double, _dp, _vp]),
     "exa_dg_step_periodic": (C.c_int, [_vp, _vp, _vp, C.c_double, _dp, C.c_int, _vp]),
     "exa_dg_step_host": (C.c_int, [_vp, _vp, C.c_double, _dp, C.c_int]),
 }

@@ -462,6 +462,20 @@ int exa_dg_max_eigenvalue(exa_dg_plan* p, const double* u_dev, double* lambda_de
     return p->tab->maxeig(u_dev, p->ncells * lpow(p->N, p->dim), lambda_dev, (hipStream_t)stream);
 }
 
+int exa_dg_has_fused_step(const exa_dg_plan* p) { return (p && p->n_it == 0 && p->tab->fused_single) ? 1 : 0; }
+
+int exa_dg_step_fused(exa_dg_plan* p, const double* u_in_dev, double* u_out_dev, double dt, const double* dx, void* stream) {
+    if (!p || !u_in_dev || !u_out_dev || !dx || u_in_dev == u_out_dev) { set_error("exa_dg_step_fused: bad argument (input and output must differ)"); return EXA_ERR_INVALID; }
+    if (!exa_dg_has_fused_step(p)) { set_error("exa_dg_step_fused: only for the single-stage scheme (n_picard = 0) in 2-D"); return EXA_ERR_INVALID; }
+    for (int d = 0; d < p->dim; d++)
+        if (!(dx[d] > 0.0)) { set_error("dx[%d] must be > 0", d); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    double idx[3];
+    inv_dx(p, dx, idx);
+    return p->tab->fused_single(p->N, u_in_dev, u_out_dev, p->nc, dt, idx, &p->ops, (hipStream_t)stream) == 0 ? EXA_OK : EXA_ERR_HIP;
+}
+
 int exa_dg_step_periodic(exa_dg_plan* p, double* u_dev, double* trace_dev, double dt, const double* dx, int n_steps,
                          void* stream) {
     for (int s = 0; s < n_steps; s++) {

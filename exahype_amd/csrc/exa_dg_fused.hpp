@@ -1,0 +1,222 @@
+// Fused single-stage ADER-DG step in 2-D (n_picard = 0: qbar := u, Fbar := f(u) -- BASELINE configs[1], "volume +
+// Riemann only"): volume integral, face extrapolation, Rusanov flux and surface corrector in ONE launch, so the face
+// traces never travel through HBM.  Same scheme and results (to rounding) as dg_stage_a_single_kernel followed by
+// dg_stage_b_kernel; no counterpart in the reference.
+//
+// One workgroup per tile of TX x TY cells plus the ring of face neighbours (periodic wrap), all in LDS:
+//   A  load      u of the tile and its ring, AoS -> [cell][var][node]                         (coalesced)
+//   B  pencils   per (cell, direction, transverse node): fluxes at the N nodes, the four traces q/F at L/R -> face
+//                table; interior cells also the volume term (kept in registers, added direction by direction)
+//   C  faces     per (face, node): face-wide max of the eigenvalues the pencils left in a table (no shuffle, any N),
+//                Rusanov flux F* -> table; then the pencils of the interior cells apply the lift
+//   D  store     u of the tile                                                                 (coalesced)
+// HBM traffic per cell: (1 + ring/tile) reads + 1 write of its DoF (1 920 B at p = 3 with 4 x 4 tiles before L2 hits on
+// the shared rings; 6 400 B for the two-kernel path, 3 840 B for the survey's fused ideal with traces in HBM).
+// Needs separate input and output arrays (neighbouring tiles read what this one would overwrite).
+#pragma once
+#include "exa_dg_kernels.hpp"
+
+namespace exa {
+
+template <int N> struct FusedTile { static constexpr int T = N <= 4 ? 4 : (N <= 6 ? 3 : 2); };
+
+template <int N, class PDE, int TX, int TY> struct FusedSingle {
+    static constexpr int NV = PDE::NV, NN = N * N;
+    static constexpr int LX = TX + 2, LY = TY + 2, LC = LX * LY;
+    static constexpr int CS = NV * NN;                          // doubles per cell
+    static constexpr int NFX = (TX + 1) * TY, NFY = TX * (TY + 1), NFACE = NFX + NFY;
+    static constexpr int FS = 2 * 2 * NV * N;                   // per face: [side][field q|F][var][node]
+    static constexpr int LAMO = LC * CS + NFACE * FS;           // offset of the eigenvalue table [face][side][node]
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(LAMO + NFACE * 2 * N);
+    static constexpr int T_INT = TX * TY * 2 * N, T_HX = 2 * TY * N, T_HY = 2 * TX * N;
+    static constexpr int NT = 256;
+    static_assert(T_INT + T_HX + T_HY <= NT, "one pencil task per lane");
+    static_assert(NFACE * N <= NT, "one face task per lane");
+};
+
+template <int N, class PDE, int TX, int TY>
+__global__ void __launch_bounds__(256)
+dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, long ncx, long ncy, long tiles_y, double dt,
+                       double idx0, double idx1, const void* __restrict__ ops_raw) {
+    using FU = FusedSingle<N, PDE, TX, TY>;
+    constexpr int NV = PDE::NV, NN = N * N, LY = FU::LY, LC = FU::LC, CS = FU::CS;
+    constexpr int NFX = FU::NFX, NFACE = FU::NFACE, FS = FU::FS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* U = lds;
+    double* FT = lds + LC * CS;
+    double* LAM = lds + FU::LAMO;
+    const int tid = threadIdx.x;
+    const long tx0 = (blockIdx.x / tiles_y) * TX, ty0 = (blockIdx.x % tiles_y) * TY;
+    const double idx[2] = {idx0, idx1};
+
+    // ---- A: load the tile and its ring (corners are never used); global cell of every local cell first (one lane
+    //      each: the periodic wrap costs 64-bit remainders, far too slow to repeat per element)
+    __shared__ long gcell[LC];
+    if (tid < LC) {
+        const int lx = tid / LY - 1, ly = tid % LY - 1;
+        long g = -1;
+        if (!((lx < 0 || lx >= TX) && (ly < 0 || ly >= TY))) {
+            const long gx = ((tx0 + lx) % ncx + ncx) % ncx, gy = ((ty0 + ly) % ncy + ncy) % ncy;
+            g = gx * ncy + gy;
+        }
+        gcell[tid] = g;
+    }
+    __syncthreads();
+    {
+        constexpr int PER = (LC * CS + FU::NT - 1) / FU::NT;     // all loads of a lane in flight before the first use
+        double tmp[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int e = tid + k * FU::NT;
+            const int lc = e < LC * CS ? e / CS : 0;
+            const long g = gcell[lc];
+            tmp[k] = (e < LC * CS && g >= 0) ? u_in[g * CS + (e - lc * CS)] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int e = tid + k * FU::NT;
+            if (e < LC * CS) {
+                const int lc = e / CS, r = e - lc * CS;
+                const int n = r / NV, v = r - n * NV;
+                U[lc * CS + v * NN + n] = tmp[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pencil task of this lane: interior cells both directions, ring cells the direction that faces the tile
+    int p_lx = 0, p_ly = 0, p_d = 0, p_t = 0;
+    bool p_task = true, p_int = false;
+    {
+        int k = tid;
+        if (k < FU::T_INT) {                                     // direction slowest: waves are (mostly) direction-uniform
+            p_int = true;
+            p_t = k % N; k /= N;
+            p_ly = k % TY; k /= TY;
+            p_lx = k % TX; p_d = k / TX;
+        } else if ((k -= FU::T_INT) < FU::T_HX) {
+            p_d = 0;
+            p_t = k % N; k /= N;
+            p_ly = k % TY; p_lx = (k / TY) ? TX : -1;
+        } else if ((k -= FU::T_HX) < FU::T_HY) {
+            p_d = 1;
+            p_t = k % N; k /= N;
+            p_lx = k % TX; p_ly = (k / TX) ? TY : -1;
+        } else {
+            p_task = false;
+        }
+    }
+    const int p_lc = (p_lx + 1) * LY + p_ly + 1;
+    const int p_n0 = p_d == 0 ? p_t : p_t * N;                    // first node of the pencil, stride p_ns
+    const int p_ns = p_d == 0 ? N : 1;
+    // faces of the pencil's cell along p_d: index or -1 (outside the tile's face table)
+    int fL = -1, fR = -1;
+    if (p_task) {
+        if (p_d == 0) {
+            if (p_lx >= 0) fL = p_lx * TY + p_ly;
+            if (p_lx + 1 <= TX) fR = (p_lx + 1) * TY + p_ly;
+        } else {
+            if (p_ly >= 0) fL = NFX + p_lx * (TY + 1) + p_ly;
+            if (p_ly + 1 <= TY) fR = NFX + p_lx * (TY + 1) + p_ly + 1;
+        }
+    }
+
+    // ---- B: fluxes, traces, volume term
+    double vol[N][NV];
+    if (p_task) {
+        const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+        double F[N][NV], q[N][NV];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double a[PDE::NAUX];
+#pragma unroll
+            for (int v = 0; v < NV; v++) q[j][v] = U[p_lc * CS + v * NN + p_n0 + j * p_ns];
+            PDE::aux_fast(q[j], a);
+#pragma unroll
+            for (int v = 0; v < NV; v++) F[j][v] = 0.0;
+            if (p_d == 0) PDE::template flux<0>(q[j], a, F[j]);
+            else PDE::template flux<1>(q[j], a, F[j]);
+        }
+        double qL[NV], qR[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            double FL = 0.0, FR = 0.0;
+            qL[v] = 0.0;
+            qR[v] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                qL[v] += o->phiL[j] * q[j][v];
+                qR[v] += o->phiR[j] * q[j][v];
+                FL += o->phiL[j] * F[j][v];
+                FR += o->phiR[j] * F[j][v];
+            }
+            if (fL >= 0) {                                       // this cell is the "+" side of its L face
+                FT[fL * FS + ((1 * 2 + 0) * NV + v) * N + p_t] = qL[v];
+                FT[fL * FS + ((1 * 2 + 1) * NV + v) * N + p_t] = FL;
+            }
+            if (fR >= 0) {                                       // and the "-" side of its R face
+                FT[fR * FS + ((0 * 2 + 0) * NV + v) * N + p_t] = qR[v];
+                FT[fR * FS + ((0 * 2 + 1) * NV + v) * N + p_t] = FR;
+            }
+        }
+        // eigenvalue of each trace state once, here (the face tasks only take the maximum)
+        if (fL >= 0) LAM[(fL * 2 + 1) * N + p_t] = PDE::maxeig_fast(qL, p_d);
+        if (fR >= 0) LAM[(fR * 2 + 0) * N + p_t] = PDE::maxeig_fast(qR, p_d);
+        if (p_int) {
+            const double sc = dt * idx[p_d];
+#pragma unroll
+            for (int i = 0; i < N; i++)
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    double sv = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; j++) sv += o->Kxi[i * N + j] * F[j][v];
+                    vol[i][v] = sc * o->iw[i] * sv;
+                }
+        }
+    }
+    __syncthreads();                                             // every pencil has read the original u, tables complete
+
+    // ---- C1: Rusanov flux per (face, node) with the face-wide max eigenvalue; F* overwrites the lane's own q- slot
+    if (tid < NFACE * N) {
+        const int f = tid / N, t = tid - f * N;
+        double* ft = FT + f * FS;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2 * N; k++) s = fmax(s, LAM[f * 2 * N + k]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const double qm = ft[((0 * 2 + 0) * NV + v) * N + t], Fm = ft[((0 * 2 + 1) * NV + v) * N + t];
+            const double qp = ft[((1 * 2 + 0) * NV + v) * N + t], Fp = ft[((1 * 2 + 1) * NV + v) * N + t];
+            ft[((0 * 2 + 0) * NV + v) * N + t] = 0.5 * (Fm + Fp) - 0.5 * s * (qp - qm);
+        }
+    }
+    __syncthreads();
+    // ---- C2: volume term + surface corrector, direction by direction (two pencils share every node)
+    for (int d = 0; d < 2; d++) {
+        if (p_int && p_d == d) {
+            const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+            const double sc = dt * idx[d];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                const double FsL = FT[fL * FS + v * N + p_t], FsR = FT[fR * FS + v * N + p_t];
+#pragma unroll
+                for (int i = 0; i < N; i++)
+                    U[p_lc * CS + v * NN + p_n0 + i * p_ns] += vol[i][v] - sc * o->iw[i] * (o->phiR[i] * FsR - o->phiL[i] * FsL);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- D: store the tile
+    for (int e = tid; e < TX * TY * CS; e += FU::NT) {
+        const int c = e / CS, r = e - c * CS;
+        const int lx = c / TY, ly = c - lx * TY;
+        const long gx = tx0 + lx, gy = ty0 + ly;
+        if (gx >= ncx || gy >= ncy) continue;                    // partial tile at the end of the block
+        const int n = r / NV, v = r - n * NV;
+        u_out[(gx * ncy + gy) * CS + r] = U[((lx + 1) * LY + ly + 1) * CS + v * NN + n];
+    }
+}
+
+}  // namespace exa

@@ -13,6 +13,7 @@
 //   flux_scaled<d>(q, a, s, F) s * F[NV] with the scale folded into the two cached scalars
 //   flux_rt(q, d, F)           same, run-time normal, no cache (FV path, traces)
 //   maxeig(q, d)               largest absolute eigenvalue along d
+//   maxeig_fast(q, d)          same to rounding with the fast reciprocal / square root (ADER-DG kernels)
 //
 // Arithmetic order follows Functions.cpp exactly (irho first, p from irho, coeff =
 // irho*Q[normal+1], F[normal+1] += p), so results agree with the CPU path to
@@ -33,6 +34,18 @@ __device__ inline double fast_rcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
+}
+
+// sqrt(x) for x >= 0 from v_rsq_f64 + two Goldschmidt steps (<= 1 ulp), a quarter of the IEEE sequence
+__device__ inline double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    return x > 0.0 ? g : 0.0;
 }
 
 // Functions.cpp:9-62 as the reference compiles it (`Dimensions` undefined -> 2-D
@@ -85,6 +98,14 @@ struct EulerRef2D {
         const double p = (GAMMA - 1) * (q[3] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2]));
         const double c = sqrt(GAMMA * fabs(p) * irho);
         const double un = q[d + 1] * irho;
+        return fmax(fabs(un - c), fabs(un + c));
+    }
+    // same value to rounding (fast reciprocal and square root, no dynamic register index); ADER-DG kernels only
+    __device__ static inline double maxeig_fast(const double* q, int d) {
+        const double irho = fast_rcp(fabs(q[0]));
+        const double p = (GAMMA - 1) * (q[3] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2]));
+        const double c = fast_sqrt(GAMMA * fabs(p) * irho);
+        const double un = (d == 0 ? q[1] : q[2]) * irho;
         return fmax(fabs(un - c), fabs(un + c));
     }
 };
@@ -143,6 +164,13 @@ struct Euler {
         const double un = q[d + 1] * irho;
         return fmax(fabs(un - c), fabs(un + c));
     }
+    __device__ static inline double maxeig_fast(const double* q, int d) {
+        const double irho = fast_rcp(fabs(q[0]));
+        const double p = (GAMMA - 1) * (q[4] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+        const double c = fast_sqrt(GAMMA * fabs(p) * irho);
+        const double un = (d == 0 ? q[1] : (d == 1 ? q[2] : q[3])) * irho;
+        return fmax(fabs(un - c), fabs(un + c));
+    }
 };
 
 // Linear advection of NVARS variables with a fixed velocity (known-answer tests).
@@ -167,6 +195,7 @@ template <int NVARS> struct Advection {
         for (int v = 0; v < NV; v++) F[v] = vel(d) * q[v];
     }
     __device__ static inline double maxeig(const double*, int d) { return fabs(vel(d)); }
+    __device__ static inline double maxeig_fast(const double*, int d) { return fabs(vel(d)); }
 };
 
 }  // namespace exa

@@ -227,7 +227,7 @@ class AderDgSolver:
     """
 
     def __init__(self, dim, N, ncells, pde=PDE_EULER, n_vars=5, n_picard=-1, dx=None, device=0, part=None,
-                 backend_is_gloo=False):
+                 backend_is_gloo=False, fused_single_stage=True):
         torch = _torch()
         self.lib = _lib.load()
         self.dim, self.N, self.nv, self.pde = dim, N, n_vars, pde
@@ -247,6 +247,8 @@ class AderDgSolver:
         assert self.u.numel() == self.lib.exa_dg_dof_count(h) and self.trace.numel() == self.lib.exa_dg_trace_count(h)
         self.part = part
         self.halo = None
+        self._fused = bool(fused_single_stage) and bool(self.lib.exa_dg_has_fused_step(h))
+        self._u2 = None
         if part is not None and part.world > 1:
             self.halo = HaloExchange(part, self.nc, self.ts, self.dev, stage_through_host=backend_is_gloo)
             self.comm_stream = torch.cuda.Stream(device=self.dev)
@@ -297,6 +299,16 @@ class AderDgSolver:
         """One ADER-DG time step of the block (periodic, or one shard of a periodic grid)."""
         torch = _torch()
         if self.halo is None:
+            if self._fused:
+                # single-stage 2-D scheme on one periodic block: one fused launch, traces stay on chip (exa_dg_fused.hpp);
+                # u ping-pongs with a second array
+                # (self.u is rebound: fetch it again after a step rather than holding on to the tensor)
+                if self._u2 is None:
+                    self._u2 = torch.empty_like(self.u)
+                check(self.lib.exa_dg_step_fused(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(self._u2.data_ptr()),
+                                                 dt, darr(self.dx), _stream_ptr()))
+                self.u, self._u2 = self._u2, self.u
+                return
             self.predictor_volume(dt)
             self.riemann_corrector(dt)
             return

@@ -275,3 +275,23 @@ def test_dg_full_size_conservation_128cubed(exa):
     m1 = mass()
     assert bool(torch.isfinite(s.u).all())
     assert np.max(np.abs(m1 - m0) / np.abs(m0)) < 1e-12, (m0, m1)
+
+
+@pytest.mark.parametrize("N,nc", [(4, (5, 3)), (2, (4, 4)), (8, (2, 3)), (6, (7, 4)), (3, (1, 9))])
+def test_dg_fused_single_stage_step_vs_oracle(exa, orc, N, nc):
+    """Opt-in fused single-stage 2-D step (exa_dg_step_fused: traces stay on chip) == oracle; partial tiles, tiny grids."""
+    ops = _ops(N)
+    u = euler_dg_state(tuple(nc) + (N, N), seed=900 + N)
+    dx = [1.0 / c for c in nc]
+    dt = 0.02 * min(dx) / (2 * N - 1)
+    s = exa.AderDgSolver(2, N, nc, n_picard=0, dx=dx, fused_single_stage=True)
+    assert s._fused
+    s.upload(u)
+    uo = u.reshape(-1).copy()
+    for _ in range(3):
+        s.step(dt)
+        uo = orc.aderdg_step(uo, dt, dx, ops, 2, N, 5, orc.PDE_EULER, 0, nc)
+    assert rel_err(s.download().reshape(-1), uo) < TOL
+    # not offered where it does not apply
+    assert not exa.AderDgSolver(2, N, nc, dx=dx, fused_single_stage=True)._fused
+    assert not exa.AderDgSolver(3, 3, (2, 2, 2), n_picard=0, fused_single_stage=True)._fused
