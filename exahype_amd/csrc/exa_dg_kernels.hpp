@@ -221,6 +221,52 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             qw[2 * jj + 1][v] = t2.y;
                         }
                 }
+                if constexpr (N % 2 == 0) {
+                    // even-odd form (DgOps::DEO): half the FMAs -- s_i -+ s_{N-1-i} from F_j +- F_{N-1-j}
+                    constexpr int H = N / 2;
+                    const EXA_AS4 double* Em = ops_here<N>(ops_raw)->DEO;
+                    double P[H][NV], M[H][NV];
+#pragma unroll
+                    for (int i = 0; i < H; i++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) P[i][v] = M[i][v] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < H; j++) {
+                        const int jm = N - 1 - j;                // mirror node
+                        double qa[NV], aa[NA], qb[NV], ab[NA], Fa[NV], Fb[NV];
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            qa[v] = WIDE ? qw[WIDE ? j : 0][v] : EXA_LD(off + v * NTS * SL + j * ps);
+                            qb[v] = WIDE ? qw[WIDE ? jm : 0][v] : EXA_LD(off + v * NTS * SL + jm * ps);
+                        }
+                        PDE::aux_fast(qa, aa);
+                        PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
+                        PDE::aux_fast(qb, ab);
+                        PDE::template flux_scaled<D>(qb, ab, idx[D], Fb);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
+                            Fa[v] = e;
+                            Fb[v] = o;
+                        }
+#pragma unroll
+                        for (int i = 0; i < H; i++) {
+                            const double ea = Em[j * N + i], eb = Em[j * N + H + i];
+#pragma unroll
+                            for (int v = 0; v < NV; v++) {
+                                EXA_FMA(P[i][v], ea, Fa[v]);
+                                EXA_FMA(M[i][v], eb, Fb[v]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < H; i++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            s[i][v] = M[i][v] + P[i][v];
+                            s[N - 1 - i][v] = M[i][v] - P[i][v];
+                        }
+                } else {
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     const int jm = N - 1 - j;                    // mirror node
@@ -246,6 +292,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             if (jm != j) EXA_FMA(s[N - 1 - i][v], -dij, Fb[v]);   // D[N-1-i][jm] = -D[i][j]
                         }
                     }
+                }
                 }
                 if constexpr (D > 0 && WIDE) {
 #pragma unroll

@@ -216,6 +216,54 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         const EXA_AS4 double* Dcol = ops_here<N>(ops_raw)->DT + half * HR;     // DT[j][half*HR + i]
                         const int off = opaque_v(d_ls * SL + G::pbase(D, d_t));
                         const int soff = off + half * (HR * ps);                               // first row of this task
+                        if constexpr (HS == 1 && N % 2 == 0) {
+                            // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs
+                            constexpr int H = N / 2;
+                            const EXA_AS4 double* Em = ops_here<N>(ops_raw)->DEO;
+                            double P[H][NV], M[H][NV];
+#pragma unroll
+                            for (int i = 0; i < H; i++)
+#pragma unroll
+                                for (int v = 0; v < NV; v++) P[i][v] = M[i][v] = 0.0;
+#pragma unroll
+                            for (int j = 0; j < H; j++) {
+                                double qa[NV], aa[NA], Fa[NV], qb[NV], ab[NA], Fb[NV];
+#pragma unroll
+                                for (int v = 0; v < NV; v++) {
+                                    qa[v] = lds[off + v * LG * SL + j * ps];
+                                    qb[v] = lds[off + v * LG * SL + (N - 1 - j) * ps];
+                                }
+#pragma unroll
+                                for (int k = 0; k < NA; k++) {
+                                    aa[k] = lds[AXO + off + k * LG * SL + j * ps];
+                                    ab[k] = lds[AXO + off + k * LG * SL + (N - 1 - j) * ps];
+                                }
+                                PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
+                                PDE::template flux_scaled<D>(qb, ab, idx[D], Fb);
+#pragma unroll
+                                for (int v = 0; v < NV; v++) {
+                                    const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
+                                    Fa[v] = e;
+                                    Fb[v] = o;
+                                }
+#pragma unroll
+                                for (int i = 0; i < H; i++) {
+                                    const double ea = Em[j * N + i], eb = Em[j * N + H + i];
+#pragma unroll
+                                    for (int v = 0; v < NV; v++) {
+                                        P[i][v] += ea * Fa[v];
+                                        M[i][v] += eb * Fb[v];
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < H; i++)
+#pragma unroll
+                                for (int v = 0; v < NV; v++) {
+                                    s[i][v] = M[i][v] + P[i][v];
+                                    s[N - 1 - i][v] = M[i][v] - P[i][v];
+                                }
+                        } else {
 #pragma unroll
                         for (int i = 0; i < HR; i++)
 #pragma unroll
@@ -234,6 +282,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
 #pragma unroll
                                 for (int v = 0; v < NV; v++) s[i][v] += dij * F[v];
                             }
+                        }
                         }
                         if constexpr (D > 0) {
 #pragma unroll
