@@ -22,10 +22,17 @@ int main() {
     CellBox box; for (int d = 0; d < 3; d++) { box.nc[d] = nc; box.lo[d] = 0; box.nb[d] = nc; } box.nbox = ncells;
     for (int rep = 0; rep < 2; rep++) {
         unsigned long long z[48] = {0};
+#ifdef EXA_STAMPS
         hipMemcpyToSymbol(HIP_SYMBOL(g_exa_stamps), z, sizeof(z));
+#endif
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0);
         hipLaunchKernelGGL(kern, dim3(ncells), dim3(SA::NT), SA::LDS_BYTES, 0, u, u, tr, ncells, box, 1e-5, nc * 1.0, nc * 1.0, nc * 1.0, N, ops);
-        hipDeviceSynchronize();
+        hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep == 1) printf("launch %.3f ms\n", ms);
+#ifdef EXA_STAMPS
         hipMemcpyFromSymbol(z, HIP_SYMBOL(g_exa_stamps), sizeof(z));
+#endif
         const char* names[12] = {"load+init", "D work", "D barrier", "T work", "T barrier", "T: loads done", "-", "avg (F1)", "vol+traces (F2)", "store (F3)", "z store", "z barrier"};
         if (rep == 0) continue;
         printf("cycles per cell, first wave of each direction group (x, y, z):\n");
