@@ -44,6 +44,9 @@
 #define EXA_ABL_COND_SLAB
 #endif
 
+// 8-byte LDS load that the back-end cannot pair into ds_read2_b64 (half the LDS rate of two ds_read_b64)
+#define EXA_SLD(i) (*(const volatile __attribute__((address_space(3))) double*)(&lds[i]))
+
 namespace exa {
 
 // Opaque copies: values derived from them cannot be hoisted out of the step loop (the compiler otherwise
@@ -230,13 +233,13 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                                 double qa[NV], aa[NA], Fa[NV], qb[NV], ab[NA], Fb[NV];
 #pragma unroll
                                 for (int v = 0; v < NV; v++) {
-                                    qa[v] = lds[off + v * LG * SL + j * ps];
-                                    qb[v] = lds[off + v * LG * SL + (N - 1 - j) * ps];
+                                    qa[v] = EXA_SLD(off + v * LG * SL + j * ps);
+                                    qb[v] = EXA_SLD(off + v * LG * SL + (N - 1 - j) * ps);
                                 }
 #pragma unroll
                                 for (int k = 0; k < NA; k++) {
-                                    aa[k] = lds[AXO + off + k * LG * SL + j * ps];
-                                    ab[k] = lds[AXO + off + k * LG * SL + (N - 1 - j) * ps];
+                                    aa[k] = EXA_SLD(AXO + off + k * LG * SL + j * ps);
+                                    ab[k] = EXA_SLD(AXO + off + k * LG * SL + (N - 1 - j) * ps);
                                 }
                                 PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
                                 PDE::template flux_scaled<D>(qb, ab, idx[D], Fb);
@@ -272,9 +275,9 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         for (int j = 0; j < N; j++) {
                             double q[NV], a[NA], F[NV];
 #pragma unroll
-                            for (int v = 0; v < NV; v++) q[v] = lds[off + v * LG * SL + j * ps];
+                            for (int v = 0; v < NV; v++) q[v] = EXA_SLD(off + v * LG * SL + j * ps);
 #pragma unroll
-                            for (int k = 0; k < NA; k++) a[k] = lds[AXO + off + k * LG * SL + j * ps];
+                            for (int k = 0; k < NA; k++) a[k] = EXA_SLD(AXO + off + k * LG * SL + j * ps);
                             PDE::template flux_scaled<D>(q, a, idx[D], F);
 #pragma unroll
                             for (int i = 0; i < HR; i++) {
@@ -339,9 +342,9 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
 #pragma unroll
                             for (int v = 0; v < NV; v++) {
                                 const int p = (v * LG + ls) * SL + o_off;
-                                Sx[v] = lds[p];
-                                Sy[v] = lds[p + QSZ];
-                                Sz[v] = lds[p + 2 * QSZ];
+                                Sx[v] = EXA_SLD(p);
+                                Sy[v] = EXA_SLD(p + QSZ);
+                                Sz[v] = EXA_SLD(p + 2 * QSZ);
                             }
 #pragma unroll
                             for (int v = 0; v < NV; v++) S[v] = Sx[v] + Sy[v] + Sz[v];
@@ -458,8 +461,8 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 double qb[N], Fb[N];
 #pragma unroll
                 for (int j = 0; j < N; j++) {
-                    qb[j] = lds[v * SL + pb + j * ps];
-                    Fb[j] = lds[((1 + d) * NV + v) * SL + pb + j * ps];
+                    qb[j] = EXA_SLD(v * SL + pb + j * ps);
+                    Fb[j] = EXA_SLD(((1 + d) * NV + v) * SL + pb + j * ps);
                 }
                 const double sc = dt * idx[d];
 #pragma unroll
