@@ -16,6 +16,9 @@
 #pragma once
 #include "exa_dg_kernels.hpp"
 
+// 8-byte LDS load that the back-end cannot pair into ds_read2_b64 (half the LDS rate of two ds_read_b64)
+#define EXA_FLD(ptr) (*(const volatile __attribute__((address_space(3))) double*)(ptr))
+
 namespace exa {
 
 template <int N> struct FusedTile { static constexpr int T = N <= 4 ? 4 : (N <= 6 ? 3 : 2); };
@@ -130,7 +133,7 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
         for (int j = 0; j < N; j++) {
             double a[PDE::NAUX];
 #pragma unroll
-            for (int v = 0; v < NV; v++) q[j][v] = U[p_lc * CS + v * NN + p_n0 + j * p_ns];
+            for (int v = 0; v < NV; v++) q[j][v] = EXA_FLD(&U[p_lc * CS + v * NN + p_n0 + j * p_ns]);
             PDE::aux_fast(q[j], a);
 #pragma unroll
             for (int v = 0; v < NV; v++) F[j][v] = 0.0;
@@ -183,11 +186,11 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
         double* ft = FT + f * FS;
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) s = fmax(s, LAM[f * 2 * N + k]);
+        for (int k = 0; k < 2 * N; k++) s = fmax(s, EXA_FLD(&LAM[f * 2 * N + k]));
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            const double qm = ft[((0 * 2 + 0) * NV + v) * N + t], Fm = ft[((0 * 2 + 1) * NV + v) * N + t];
-            const double qp = ft[((1 * 2 + 0) * NV + v) * N + t], Fp = ft[((1 * 2 + 1) * NV + v) * N + t];
+            const double qm = EXA_FLD(&ft[((0 * 2 + 0) * NV + v) * N + t]), Fm = EXA_FLD(&ft[((0 * 2 + 1) * NV + v) * N + t]);
+            const double qp = EXA_FLD(&ft[((1 * 2 + 0) * NV + v) * N + t]), Fp = EXA_FLD(&ft[((1 * 2 + 1) * NV + v) * N + t]);
             ft[((0 * 2 + 0) * NV + v) * N + t] = 0.5 * (Fm + Fp) - 0.5 * s * (qp - qm);
         }
     }
@@ -199,10 +202,10 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
             const double sc = dt * idx[d];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                const double FsL = FT[fL * FS + v * N + p_t], FsR = FT[fR * FS + v * N + p_t];
+                const double FsL = EXA_FLD(&FT[fL * FS + v * N + p_t]), FsR = EXA_FLD(&FT[fR * FS + v * N + p_t]);
 #pragma unroll
                 for (int i = 0; i < N; i++)
-                    U[p_lc * CS + v * NN + p_n0 + i * p_ns] += vol[i][v] - sc * o->iw[i] * (o->phiR[i] * FsR - o->phiL[i] * FsL);
+                    U[p_lc * CS + v * NN + p_n0 + i * p_ns] = EXA_FLD(&U[p_lc * CS + v * NN + p_n0 + i * p_ns]) + vol[i][v] - sc * o->iw[i] * (o->phiR[i] * FsR - o->phiL[i] * FsL);
             }
         }
         __syncthreads();
