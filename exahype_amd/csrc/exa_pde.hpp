@@ -26,13 +26,19 @@ namespace exa {
 
 constexpr double GAMMA = 1.4;
 
-// 1/x from v_rcp_f64 + two Newton steps: <= 1 ulp, a third of the instructions of the IEEE division
-// sequence.  Used by the ADER-DG kernels only (tolerance 1e-10); the FV faithful kernel keeps the
-// correctly rounded division the reference's CPU build performs.
+// 1/x from v_rcp_f64 + EXA_RCP_NR Newton steps.  Measured on MI355X against the IEEE quotient
+// (scripts/rcp_accuracy.hip, 4M values): bare v_rcp_f64 2.6e8 ulp, one step <= 11 ulp (2.5e-15 relative), two
+// steps exact.  One step is the default: used by the ADER-DG kernels only (tolerance 1e-10; 2 % of stage A);
+// the FV faithful kernel keeps the correctly rounded division the reference's CPU build performs.
+#ifndef EXA_RCP_NR
+#define EXA_RCP_NR 1
+#endif
 __device__ inline double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
+#if EXA_RCP_NR >= 2
     r = fma(fma(-x, r, 1.0), r, r);
+#endif
     return r;
 }
 
