@@ -159,18 +159,16 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     const int v0 = grp * NVA < NV ? grp * NVA : NV, v1 = (grp + 1) * NVA < NV ? (grp + 1) * NVA : NV;
 
     __syncthreads();                                             // cell_id visible
-    // ---- load u (both lanes of a pair read the node: 40 contiguous bytes), q_l := u for every l
+    // ---- load u (every group reads the node: 40 contiguous bytes), q_0 := u
     double ur[NV];
     {
         const long cell = t_task ? cell_id[tc] : -1;
 #pragma unroll
         for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + tn) * NV + v] : 1.0;   // (every group reads the node: L1-resident)
-        if (t_task && n_it > 0) {
+        if (t_task && n_it > 0) {                                // level 0 only: iteration 0 reads nothing else, its update writes all
 #pragma unroll
-            for (int l = 0; l < N; l++)
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-                    if (v >= v0 && v < v1) lds[toff + (v * NTS + l) * SL] = ur[v];
+            for (int v = 0; v < NV; v++)
+                if (v >= v0 && v < v1) lds[toff + (v * NTS + 0) * SL] = ur[v];
         }
     }
     // A group with fewer than NVA variables repeats its last one (same lane, same values, same addresses; its loads are
@@ -394,55 +392,56 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         EXA_STAMP(4);
     }
 
-    // ---- time averages (A.3) per node: qbar -> A slab 0, Fbar_d -> A slab 1+d; then u -> Q slab 0
+    // ---- time averages (A.3) per node, one direction per group (all waves busy; q is re-read by each group):
+    //      Fbar_d -> A slab 1+d; group 0 also qbar -> A slab 0 and u -> B slab 0 (S_y, S_z are dead)
     {
-        double un[NV], qb[NV], Fb[DIM][NV];
-        const int c = tid / NN, n = tid - c * NN;
+        const int c = bt / NN, n = bt - c * NN;
         const int off = c * CS + G::node_off(n);
-        if (tid < TD) {
-            const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
+        if (bt < TD) {
+            static_for<0, DIM>([&](auto dc) {
+                constexpr int D = decltype(dc)::value;
+                if (grp == D) {
+                    const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
+                    double un[NV], qb[NV], Fb[NV];
 #pragma unroll
-            for (int v = 0; v < NV; v++) qb[v] = 0.0;
+                    for (int v = 0; v < NV; v++) qb[v] = Fb[v] = 0.0;
+                    const long cell = cell_id[c];
+                    if (D == 0 || n_it == 0) {
 #pragma unroll
-            for (int d = 0; d < DIM; d++)
+                        for (int v = 0; v < NV; v++) un[v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
+                    }
+                    if (n_it > 0) {
 #pragma unroll
-                for (int v = 0; v < NV; v++) Fb[d][v] = 0.0;
-            const long cell = cell_id[c];
+                        for (int l = 0; l < N; l++) {
+                            double q[NV], a[NA], F[NV];
 #pragma unroll
-            for (int v = 0; v < NV; v++) un[v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
-            if (n_it > 0) {
+                            for (int v = 0; v < NV; v++) q[v] = EXA_LD(off + (v * NTS + l) * SL);
+                            PDE::aux_fast(q, a);
+                            if constexpr (D == 0) {
 #pragma unroll
-                for (int l = 0; l < N; l++) {
-                    double q[NV], a[NA], F[NV];
+                                for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[v];
+                            }
+                            PDE::template flux<D>(q, a, F);
 #pragma unroll
-                    for (int v = 0; v < NV; v++) q[v] = lds[off + (v * NTS + l) * SL];
-                    PDE::aux_fast(q, a);
+                            for (int v = 0; v < NV; v++) Fb[v] += wm[l] * F[v];
+                        }
+                    } else {
+                        double a[NA];
+                        PDE::aux_fast(un, a);
 #pragma unroll
-                    for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[v];
-                    static_for<0, DIM>([&](auto dc) {
-                        constexpr int D = decltype(dc)::value;
-                        PDE::template flux<D>(q, a, F);
+                        for (int v = 0; v < NV; v++) qb[v] = un[v];
+                        PDE::template flux<D>(un, a, Fb);
+                    }
 #pragma unroll
-                        for (int v = 0; v < NV; v++) Fb[D][v] += wm[l] * F[v];
-                    });
+                    for (int v = 0; v < NV; v++) {
+                        lds[off + ASZ + (v * NTS + 1 + D) * SL] = Fb[v];
+                        if constexpr (D == 0) {
+                            lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
+                            lds[off + 2 * ASZ + (v * NTS + 0) * SL] = un[v];
+                        }
+                    }
                 }
-            } else {
-                double a[NA];
-                PDE::aux_fast(un, a);
-#pragma unroll
-                for (int v = 0; v < NV; v++) qb[v] = un[v];
-                static_for<0, DIM>([&](auto dc) {
-                    constexpr int D = decltype(dc)::value;
-                    PDE::template flux<D>(un, a, Fb[D]);
-                });
-            }
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
-#pragma unroll
-                for (int d = 0; d < DIM; d++) lds[off + ASZ + (v * NTS + 1 + d) * SL] = Fb[d][v];
-                lds[off + (v * NTS + 0) * SL] = un[v];           // own column of Q only
-            }
+            });
         }
     }
     __syncthreads();
@@ -500,7 +499,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         const int c = task / (NN * NV), e = task - c * (NN * NV);
         const int n = e / NV, v = e - n * NV;
         const int off = c * CS + G::node_off(n) + v * NTS * SL;
-        double us = lds[off];
+        double us = lds[off + 2 * ASZ];                          // u (B slab 0)
 #pragma unroll
         for (int d = 0; d < DIM; d++) us += lds[off + (1 + d) * SL];
         const long cell = cell_id[c];
