@@ -140,15 +140,13 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     constexpr int ASZ = SA::ASZ, CS = SA::CS;
     constexpr int NJ = (N + 1) / 2;                          // columns of D kept (centro-antisymmetry)
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ long cell_id[CPB];
+    __shared__ long cell_ids[2][CPB];                            // this block's cells | the next block's (ping-pong)
 
     const int tid = threadIdx.x;
     EXA_STAMP_INIT();
     const int grp = __builtin_amdgcn_readfirstlane(tid / GW);   // wave-uniform direction group
     const int bt = tid - grp * GW;                               // task index inside the group
-    const long b0 = (long)blockIdx.x * CPB;
     const double idx[3] = {idx0, idx1, idx2};
-    if (tid < CPB) cell_id[tid] = box.cell(b0 + tid);
 
     // ---- time-update role of this thread: node bt, the variables [v0, v1) of its direction group
     // (the update is split by variable over the DIM groups, so all waves take part in it)
@@ -158,14 +156,25 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     const int toff = tc * CS + G::node_off(tn);
     const int v0 = grp * NVA < NV ? grp * NVA : NV, v1 = (grp + 1) * NVA < NV ? (grp + 1) * NVA : NV;
 
-    __syncthreads();                                             // cell_id visible
-    // ---- load u (every group reads the node: 40 contiguous bytes), q_0 := u
-    double ur[NV];
+    // Persistent grid: a workgroup walks over blocks of CPB cells (blk, blk + gridDim.x, ...) and fetches the next
+    // block's u while it works on this one -- with one workgroup per CU (LDS) nothing else would hide that latency.
+    const long nblocks = (box.nbox + CPB - 1) / CPB;
+    long blk = blockIdx.x;
+    int par = 0;
+    if (tid < CPB) cell_ids[0][tid] = box.cell(blk * CPB + tid);
+    __syncthreads();                                             // cell ids visible
+    double ur[NV];                                               // u of node (tc, tn) (every group reads it: 40 contiguous bytes)
     {
-        const long cell = t_task ? cell_id[tc] : -1;
+        const long cell = bt < TD ? cell_ids[0][tc] : -1;
 #pragma unroll
-        for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + tn) * NV + v] : 1.0;   // (every group reads the node: L1-resident)
-        if (t_task && n_it > 0) {                                // level 0 only: iteration 0 reads nothing else, its update writes all
+        for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + tn) * NV + v] : 1.0;
+    }
+    for (; blk < nblocks; blk += gridDim.x, par ^= 1) {
+    const long* cell_id = cell_ids[par];
+    {
+        const long nblk = blk + gridDim.x;
+        if (tid < CPB) cell_ids[par ^ 1][tid] = nblk < nblocks ? box.cell(nblk * CPB + tid) : -1;
+        if (t_task && n_it > 0) {                                // q_0 := u; level 0 only: iteration 0 reads nothing else, its update writes all
 #pragma unroll
             for (int v = 0; v < NV; v++)
                 if (v >= v0 && v < v1) lds[toff + (v * NTS + 0) * SL] = ur[v];
@@ -187,6 +196,12 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         ur_mine[vv] = x;
     }
     __syncthreads();
+    double un[NV];                                               // u of the next block's node, in flight during this block
+    {
+        const long cn = bt < TD ? cell_ids[par ^ 1][tc] : -1;
+#pragma unroll
+        for (int v = 0; v < NV; v++) un[v] = cn >= 0 ? u_in[(cn * NN + tn) * NV + v] : 1.0;
+    }
     EXA_STAMP(0);
 
     // ---- Picard iterations (A.2):  q <- u - dt * T * sum_d (1/dx_d) D_d f_d(q)
@@ -402,14 +417,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 constexpr int D = decltype(dc)::value;
                 if (grp == D) {
                     const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
-                    double un[NV], qb[NV], Fb[NV];
+                    double qb[NV], Fb[NV];
 #pragma unroll
                     for (int v = 0; v < NV; v++) qb[v] = Fb[v] = 0.0;
-                    const long cell = cell_id[c];
-                    if (D == 0 || n_it == 0) {
-#pragma unroll
-                        for (int v = 0; v < NV; v++) un[v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
-                    }
                     if (n_it > 0) {
 #pragma unroll
                         for (int l = 0; l < N; l++) {
@@ -427,17 +437,17 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         }
                     } else {
                         double a[NA];
-                        PDE::aux_fast(un, a);
+                        PDE::aux_fast(ur, a);
 #pragma unroll
-                        for (int v = 0; v < NV; v++) qb[v] = un[v];
-                        PDE::template flux<D>(un, a, Fb);
+                        for (int v = 0; v < NV; v++) qb[v] = ur[v];
+                        PDE::template flux<D>(ur, a, Fb);
                     }
 #pragma unroll
                     for (int v = 0; v < NV; v++) {
                         lds[off + ASZ + (v * NTS + 1 + D) * SL] = Fb[v];
                         if constexpr (D == 0) {
                             lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
-                            lds[off + 2 * ASZ + (v * NTS + 0) * SL] = un[v];
+                            lds[off + 2 * ASZ + (v * NTS + 0) * SL] = ur[v];   // same (cell, node) as the update role of this lane
                         }
                     }
                 }
@@ -506,6 +516,10 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         if (cell >= 0) u_out[cell * (NN * NV) + e] = us;
     }
     EXA_STAMP(9);
+    __syncthreads();                                             // LDS and the cell-id slot are reused by the next block
+#pragma unroll
+    for (int v = 0; v < NV; v++) ur[v] = un[v];
+    }
     EXA_STAMP_FLUSH();
 }
 

@@ -26,7 +26,7 @@ int main() {
         hipMemcpyToSymbol(HIP_SYMBOL(g_exa_stamps), z, sizeof(z));
 #endif
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(ncells), dim3(SA::NT), SA::LDS_BYTES, 0, u, u, tr, ncells, box, 1e-5, nc * 1.0, nc * 1.0, nc * 1.0, N, ops);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(SA::NT), SA::LDS_BYTES, 0, u, u, tr, ncells, box, 1e-5, nc * 1.0, nc * 1.0, nc * 1.0, N, ops);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep == 1) printf("launch %.3f ms\n", ms);
