@@ -21,6 +21,13 @@
 
 namespace exa {
 
+// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch): hand each XCD a contiguous range of logical blocks,
+// so that the traces a cell reads from its y/z neighbours were just touched by the same XCD's L2.
+__device__ inline long xcd_contiguous(long b, long n) {
+    const long per = n / 8;
+    return b < per * 8 ? (b % 8) * per + b / 8 : b;
+}
+
 template <int I, int E, class F> __device__ inline void static_for(F&& f) {
     if constexpr (I < E) {
         f(std::integral_constant<int, I>{});
@@ -666,7 +673,7 @@ dg_stage_b_kernel(double* __restrict__ u, const double* __restrict__ trace, Stag
     __shared__ double cL[DIM][N], cR[DIM][N];
 
     const int tid = threadIdx.x;
-    const long b0 = (long)blockIdx.x * CPB;
+    const long b0 = xcd_contiguous(blockIdx.x, gridDim.x) * CPB;
     const double idx[3] = {idx0, idx1, idx2};
     // (compile-time index into the kernarg-resident operator block: stays in SGPRs)
 #pragma unroll
@@ -786,7 +793,7 @@ dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace
     __shared__ double cL[DIM][N], cR[DIM][N];
 
     const int tid = threadIdx.x;
-    const long b0 = (long)blockIdx.x * CPB;
+    const long b0 = xcd_contiguous(blockIdx.x, gridDim.x) * CPB;
     const double idx[3] = {idx0, idx1, idx2};
     // (compile-time index into the kernarg-resident operator block: stays in SGPRs)
 #pragma unroll
