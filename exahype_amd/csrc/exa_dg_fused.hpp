@@ -49,7 +49,8 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
     double* FT = lds + LC * CS;
     double* LAM = lds + FU::LAMO;
     const int tid = threadIdx.x;
-    const long tx0 = (blockIdx.x / tiles_y) * TX, ty0 = (blockIdx.x % tiles_y) * TY;
+    const long lb = xcd_contiguous(blockIdx.x, gridDim.x);      // neighbouring tiles (shared rings) on the same XCD's L2
+    const long tx0 = (lb / tiles_y) * TX, ty0 = (lb % tiles_y) * TY;
     const double idx[2] = {idx0, idx1};
 
     // ---- A: load the tile and its ring (corners are never used); global cell of every local cell first (one lane
