@@ -38,7 +38,7 @@ _ref = None
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(HERE, "liborc.so")
+        so = os.environ.get("EXA_ORACLE_LIB") or os.path.join(HERE, "liborc.so")   # override: the sanitizer build of the tests
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
