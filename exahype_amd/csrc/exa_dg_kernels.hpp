@@ -478,8 +478,8 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             double qb[N], Fb[N];
 #pragma unroll
             for (int j = 0; j < N; j++) {
-                qb[j] = lds[off + ASZ + j * ps];
-                Fb[j] = lds[off + ASZ + (1 + d) * SL + j * ps];
+                qb[j] = EXA_LD(off + ASZ + j * ps);
+                Fb[j] = EXA_LD(off + ASZ + (1 + d) * SL + j * ps);
             }
             const double sc = dt * idx[d];
 #pragma unroll
@@ -516,9 +516,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         const int c = task / (NN * NV), e = task - c * (NN * NV);
         const int n = e / NV, v = e - n * NV;
         const int off = c * CS + G::node_off(n) + v * NTS * SL;
-        double us = lds[off + 2 * ASZ];                          // u (B slab 0)
+        double us = EXA_LD(off + 2 * ASZ);                       // u (B slab 0)
 #pragma unroll
-        for (int d = 0; d < DIM; d++) us += lds[off + (1 + d) * SL];
+        for (int d = 0; d < DIM; d++) us += EXA_LD(off + (1 + d) * SL);
         const long cell = cell_id[c];
         if (cell >= 0) u_out[cell * (NN * NV) + e] = us;
     }
