@@ -41,7 +41,7 @@ template <int DIM, int N> struct Geo {
     static constexpr int NTS = (N > DIM + 1) ? N : DIM + 1;     // slabs per variable
 
     // padded offset of lexicographic node n
-    __device__ static inline int node_off(int n) {
+    __host__ __device__ static inline int node_off(int n) {
         if constexpr (DIM == 3) return (n / (N * N)) * SI + (n % (N * N));
         else return (n / N) * SI + (n % N);
     }
@@ -57,7 +57,7 @@ template <int DIM, int N> struct Geo {
     }
     // padded offset of the first node of pencil t (t = lexicographic index of the
     // remaining axes == the face-node index y of the traces)
-    __device__ static inline int pbase(int d, int t) {
+    __host__ __device__ static inline int pbase(int d, int t) {
         if constexpr (DIM == 3) {
             if (d == 0) return t;                          // (j,k)
             if (d == 1) return (t / N) * SI + (t % N);     // (i,k)

@@ -163,6 +163,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     const int toff = tc * CS + G::node_off(tn);
     const int v0 = grp * NVA < NV ? grp * NVA : NV, v1 = (grp + 1) * NVA < NV ? (grp + 1) * NVA : NV;
 
+    // derivative-phase task of this lane (conflict-free enumeration built on the host: dg_inst.hip OpsImage), -1: none
+    const int d_task = grp < DIM ? reinterpret_cast<const int*>(static_cast<const char*>(ops_raw) + (sizeof(DgOps<N>) + 15) / 16 * 16)[grp * GW + bt] : -1;
+
     // Persistent grid: a workgroup walks over blocks of CPB cells (blk, blk + gridDim.x, ...) and fetches the next
     // block's u while it works on this one -- with one workgroup per CU (LDS) nothing else would hide that latency.
     const long nblocks = (box.nbox + CPB - 1) / CPB;
@@ -225,13 +228,13 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             constexpr int W0 = (CPB * NF + 63) / 64;
             const int wave = tid >> 6;
             const int k0 = (wave - D * W0) * 64 + (tid & 63);      // iteration-0 task of this lane for direction D
-            const bool mine = it > 0 ? (grp == D && bt < TD) : (wave >= D * W0 && wave < (D + 1) * W0 && k0 < CPB * NF);
+            const bool mine = it > 0 ? (grp == D && d_task >= 0) : (wave >= D * W0 && wave < (D + 1) * W0 && k0 < CPB * NF);
             if (mine EXA_ABL_COND_SKIP_D) {
                 constexpr int ps = G::pstride(D);
                 // D[i][N-1-j] = -D[N-1-i][j]: columns j < NJ suffice (a few SGPRs per j step)
                 const EXA_AS4 double* DTm = ops_here<N>(ops_raw)->DT;
-                const int c = it > 0 ? bt / NN : k0 / NF;
-                const int r = it > 0 ? bt - c * NN : k0 - c * NF;
+                const int c = it > 0 ? d_task / NN : k0 / NF;
+                const int r = it > 0 ? d_task - c * NN : k0 - c * NF;
                 const int l = it > 0 ? r / NF : 0, t = it > 0 ? r - l * NF : r;
                 if constexpr (D == 0) did_x = true;
                 const int off = c * CS + l * SL + G::pbase(D, t);
