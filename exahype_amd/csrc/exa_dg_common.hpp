@@ -51,7 +51,7 @@ template <int DIM, int N> struct Geo {
         else return d == 0 ? n / N : n % N;
     }
     // stride between consecutive nodes of a pencil along axis d
-    __device__ static constexpr int pstride(int d) {
+    __host__ __device__ static constexpr int pstride(int d) {
         if constexpr (DIM == 3) return d == 0 ? SI : (d == 1 ? N : 1);
         else return d == 0 ? SI : 1;
     }
