@@ -24,6 +24,8 @@ def run(dim, P, H, n_real, n_aux, n_patches, pde, mode, steps=10):
 
 if __name__ == "__main__":
     run(2, 4, 1, 5, 5, 1 << 20, exa.PDE_EULER_REF2D, exa.FV_FAITHFUL)
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":
+        sys.exit(0)
     run(2, 4, 1, 5, 5, 1 << 20, exa.PDE_EULER_REF2D, exa.FV_RUSANOV)
     run(3, 15, 1, 5, 0, 8192, exa.PDE_EULER, exa.FV_RUSANOV)
     run(3, 15, 1, 5, 0, 8192, exa.PDE_EULER, exa.FV_FAITHFUL)
