@@ -26,6 +26,7 @@
 namespace exa {
 
 constexpr int MAXV = 8;
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 // STAGE = true (small patches): the workgroup's `ppb` patches are one contiguous block of HBM; it is
 // copied into LDS with coalesced 16-byte loads and the stencil reads LDS (the AoS stencil reads straight
@@ -197,7 +198,8 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             const long pp = row / rows_pp;
             const int rr = (int)(row - pp * rows_pp);
             const long o = pp * vol * V + ((DIM == 3) ? ((long)(rr / P + H) * S * S + (long)(rr % P + H) * S + H) : ((long)(rr + H) * S + H)) * V;
-            reinterpret_cast<double2*>(dst + o)[x] = reinterpret_cast<const double2*>(fv_lds + o)[x];
+            // streaming store: the rows start at 80-byte offsets, i.e. partial cache lines -- do not allocate them in L2
+            __builtin_nontemporal_store(reinterpret_cast<const v2d*>(fv_lds + o)[x], reinterpret_cast<v2d*>(dst + o) + x);
         }
     } else {
 #pragma unroll
