@@ -17,10 +17,12 @@ template <int N> struct DgOps {
     double iw[N];       // 1 / w
     double D[N * N];    // D[i][j]   = phi_j'(xi_i)
     double DT[N * N];   // DT[j][i]  = D[i][j]  (column j of D contiguous)
-    // even-odd form of D (centro-antisymmetric: D[N-1-i][N-1-j] = -D[i][j]), h = N/2, j < h:
-    //   DEO[j][i]     = (D[i][j] + D[i][N-1-j]) / 2   acts on F_j + F_{N-1-j}:  s_i - s_{N-1-i} = 2 sum_j (..)
-    //   DEO[j][h + i] = (D[i][j] - D[i][N-1-j]) / 2   acts on F_j - F_{N-1-j}:  s_i + s_{N-1-i} = 2 sum_j (..)
-    double DEO[(N / 2) * N > 0 ? (N / 2) * N : 1];
+    // even-odd form of D (centro-antisymmetric: D[N-1-i][N-1-j] = -D[i][j]), h = N/2, j < h, jb = N-1-j:
+    //   DEO[j][i]     = (D[i][j] + D[i][jb]) / 2   acts on F_j + F_jb:  s_i - s_{N-1-i} = 2 sum_j (..)   (i < h)
+    //   DEO[j][h + i] = (D[i][j] - D[i][jb]) / 2   acts on F_j - F_jb:  s_i + s_{N-1-i} = 2 sum_j (..)
+    // odd N (middle index h): DEO[j][2h] = D[h][j] (the middle row sees only F_j - F_jb; D[h][h] = 0) and
+    //   DEO[h][i] = D[i][h] (the middle node's flux enters s_i - s_{N-1-i} with 2 D[i][h])
+    double DEO[(N / 2) * N + N / 2 + 1];
     double Kxi[N * N];  // Kxi[i][j] = w_j D[j][i]
     double T[N * N];    // T[l'][l]  = iK1[l'][l] * w_l   (time update; uses iK1*F0 = 1)
     double Tsum[N];     // sum_l T[l'][l]                  (iteration 0: the iterate is constant in time)

@@ -145,7 +145,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     constexpr int NV = PDE::NV, NA = PDE::NAUX;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL, NTS = G::NTS;
     constexpr int ASZ = SA::ASZ, CS = SA::CS;
-    constexpr int NJ = (N + 1) / 2;                          // columns of D kept (centro-antisymmetry)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ long cell_ids[2][CPB];                            // this block's cells | the next block's (ping-pong)
 
@@ -231,8 +230,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             const bool mine = it > 0 ? (grp == D && d_task >= 0) : (wave >= D * W0 && wave < (D + 1) * W0 && k0 < CPB * NF);
             if (mine EXA_ABL_COND_SKIP_D) {
                 constexpr int ps = G::pstride(D);
-                // D[i][N-1-j] = -D[N-1-i][j]: columns j < NJ suffice (a few SGPRs per j step)
-                const EXA_AS4 double* DTm = ops_here<N>(ops_raw)->DT;
                 const int c = it > 0 ? d_task / NN : k0 / NF;
                 const int r = it > 0 ? d_task - c * NN : k0 - c * NF;
                 const int l = it > 0 ? r / NF : 0, t = it > 0 ? r - l * NF : r;
@@ -257,15 +254,18 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             qw[2 * jj + 1][v] = t2.y;
                         }
                 }
-                if constexpr (N % 2 == 0) {
-                    // even-odd form (DgOps::DEO): half the FMAs -- s_i -+ s_{N-1-i} from F_j +- F_{N-1-j}
+                {
+                    // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs --
+                    // s_i -+ s_{N-1-i} from F_j +- F_{N-1-j}; odd N: the middle node and the middle row on top
                     constexpr int H = N / 2;
                     const EXA_AS4 double* Em = ops_here<N>(ops_raw)->DEO;
-                    double P[H][NV], M[H][NV];
+                    double P[H > 0 ? H : 1][NV], M[H > 0 ? H : 1][NV], mid[NV];
 #pragma unroll
                     for (int i = 0; i < H; i++)
 #pragma unroll
                         for (int v = 0; v < NV; v++) P[i][v] = M[i][v] = 0.0;
+#pragma unroll
+                    for (int v = 0; v < NV; v++) mid[v] = 0.0;
 #pragma unroll
                     for (int j = 0; j < H; j++) {
                         const int jm = N - 1 - j;                // mirror node
@@ -294,6 +294,26 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                                 EXA_FMA(M[i][v], eb, Fb[v]);
                             }
                         }
+                        if constexpr (N % 2 == 1) {
+                            const double em = Em[j * N + 2 * H];
+#pragma unroll
+                            for (int v = 0; v < NV; v++) EXA_FMA(mid[v], em, Fb[v]);
+                        }
+                    }
+                    if constexpr (N % 2 == 1) {                  // middle node
+                        double qa[NV], aa[NA], Fa[NV];
+#pragma unroll
+                        for (int v = 0; v < NV; v++) qa[v] = EXA_LD(off + v * NTS * SL + H * ps);
+                        PDE::aux_fast(qa, aa);
+                        PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
+#pragma unroll
+                        for (int i = 0; i < H; i++) {
+                            const double ec = Em[H * N + i];
+#pragma unroll
+                            for (int v = 0; v < NV; v++) EXA_FMA(P[i][v], ec, Fa[v]);
+                        }
+#pragma unroll
+                        for (int v = 0; v < NV; v++) s[H][v] = mid[v];
                     }
 #pragma unroll
                     for (int i = 0; i < H; i++)
@@ -302,33 +322,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             s[i][v] = M[i][v] + P[i][v];
                             s[N - 1 - i][v] = M[i][v] - P[i][v];
                         }
-                } else {
-#pragma unroll
-                for (int j = 0; j < NJ; j++) {
-                    const int jm = N - 1 - j;                    // mirror node
-                    double qa[NV], aa[NA], qb[NV], ab[NA], Fa[NV], Fb[NV];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) qa[v] = WIDE ? qw[WIDE ? j : 0][v] : EXA_LD(off + v * NTS * SL + j * ps);
-                    if (jm != j) {
-#pragma unroll
-                        for (int v = 0; v < NV; v++) qb[v] = WIDE ? qw[WIDE ? jm : 0][v] : EXA_LD(off + v * NTS * SL + jm * ps);
-                    }
-                    PDE::aux_fast(qa, aa);
-                    PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
-                    if (jm != j) {
-                        PDE::aux_fast(qb, ab);
-                        PDE::template flux_scaled<D>(qb, ab, idx[D], Fb);
-                    }
-#pragma unroll
-                    for (int i = 0; i < N; i++) {
-                        const double dij = DTm[j * N + i];              // D[i][j]
-#pragma unroll
-                        for (int v = 0; v < NV; v++) {
-                            EXA_FMA(s[i][v], dij, Fa[v]);
-                            if (jm != j) EXA_FMA(s[N - 1 - i][v], -dij, Fb[v]);   // D[N-1-i][jm] = -D[i][j]
-                        }
-                    }
-                }
                 }
                 if constexpr (D > 0 && WIDE) {
 #pragma unroll

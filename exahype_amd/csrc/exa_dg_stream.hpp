@@ -219,15 +219,18 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         const EXA_AS4 double* Dcol = ops_here<N>(ops_raw)->DT + half * HR;     // DT[j][half*HR + i]
                         const int off = opaque_v(d_ls * SL + G::pbase(D, d_t));
                         const int soff = off + half * (HR * ps);                               // first row of this task
-                        if constexpr (HS == 1 && N % 2 == 0) {
-                            // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs
+                        if constexpr (HS == 1) {
+                            // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs; odd N: the middle
+                            // node and the middle row on top
                             constexpr int H = N / 2;
                             const EXA_AS4 double* Em = ops_here<N>(ops_raw)->DEO;
-                            double P[H][NV], M[H][NV];
+                            double P[H][NV], M[H][NV], mid[NV];
 #pragma unroll
                             for (int i = 0; i < H; i++)
 #pragma unroll
                                 for (int v = 0; v < NV; v++) P[i][v] = M[i][v] = 0.0;
+#pragma unroll
+                            for (int v = 0; v < NV; v++) mid[v] = 0.0;
 #pragma unroll
                             for (int j = 0; j < H; j++) {
                                 double qa[NV], aa[NA], Fa[NV], qb[NV], ab[NA], Fb[NV];
@@ -258,6 +261,27 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                                         M[i][v] += eb * Fb[v];
                                     }
                                 }
+                                if constexpr (N % 2 == 1) {
+                                    const double em = Em[j * N + 2 * H];
+#pragma unroll
+                                    for (int v = 0; v < NV; v++) mid[v] += em * Fb[v];
+                                }
+                            }
+                            if constexpr (N % 2 == 1) {          // middle node
+                                double qa[NV], aa[NA], Fa[NV];
+#pragma unroll
+                                for (int v = 0; v < NV; v++) qa[v] = EXA_SLD(off + v * LG * SL + H * ps);
+#pragma unroll
+                                for (int k = 0; k < NA; k++) aa[k] = EXA_SLD(AXO + off + k * LG * SL + H * ps);
+                                PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
+#pragma unroll
+                                for (int i = 0; i < H; i++) {
+                                    const double ec = Em[H * N + i];
+#pragma unroll
+                                    for (int v = 0; v < NV; v++) P[i][v] += ec * Fa[v];
+                                }
+#pragma unroll
+                                for (int v = 0; v < NV; v++) s[H][v] = mid[v];
                             }
 #pragma unroll
                             for (int i = 0; i < H; i++)

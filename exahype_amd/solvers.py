@@ -508,8 +508,8 @@ class SubcellLimiter:
         s.step(dt)                                             # candidate DG solution everywhere
         if n == 0:
             return 0
-        if n not in self._fv:
-            self._fv[n] = FVRusanovKernel(s.dim, self.Ns, 1, s.nv, 0, n, pde=s.pde, mode=FV_RUSANOV, device=s.dev.index or 0)
+        if n not in self._fv:                                  # one plan per patch count; keep only the current one
+            self._fv = {n: FVRusanovKernel(s.dim, self.Ns, 1, s.nv, 0, n, pde=s.pde, mode=FV_RUSANOV, device=s.dev.index or 0)}
         self._fv[n].time_step(patches[:n].reshape(-1), dt, s.dx[0] / self.Ns)
         check(s.lib.exa_dg_reconstruct_patches(s._plan, C.c_void_p(patches.data_ptr()), C.c_void_p(cells.data_ptr()), n,
                                                C.c_void_p(s.u.data_ptr()), _stream_ptr()))
