@@ -91,6 +91,7 @@ class KernelBuilder:
         self.directional_items = []
         self.directional_consts = {}    # name -> value per direction
         self.functions = []
+        self.function_bodies = {}             # extension: SymPy bodies of PDE terms (see function())
         self.item_struct = {}           # 0: scalar per volume, 1: n_real, 2: n_real + n_aux
 
         full = (0, patch_size + 2 * halo_size)
@@ -144,7 +145,14 @@ class KernelBuilder:
             self.item_struct[expr + suffix] = 1 if struct else 0
         return IndexedBase(expr, real=True)
 
-    def function(self: KernelBuilder, expr: str, parent: core.basic.Basic = None, parameter_types: List = [], return_type=none, ):
+    def function(self: KernelBuilder, expr: str, parent: core.basic.Basic = None, parameter_types: List = [], return_type=none,
+                 body=None):
+        """As the reference (`exahype/KernelBuilder.py:134`).  Extension: `body`, a callable
+        `(q, normal) -> SymPy expression(s)` in the state symbols q -- for the flux a list of n_real expressions, for
+        the eigenvalue one expression.  In the reference these names resolve to host C++ at link time
+        (`Unit test/Functions.h:2-4`); a device kernel needs the terms themselves, and HIPPrinter compiles the bodies
+        of the functions named Flux/flux and maxEigenvalue when both are given.  The builder state the reference's
+        printers see is unchanged."""
         if parent != None:  # noqa: E711
             self.parents[expr] = str(parent)
         self.functions.append(expr)
@@ -152,6 +160,10 @@ class KernelBuilder:
         func.returnType(return_type)
         func.parameterTypes(parameter_types)
         self.all_items[expr] = func
+        if body is not None:
+            if not callable(body):
+                raise TypeError("body must be callable: (q, normal) -> SymPy expression(s)")
+            self.function_bodies[expr] = body
         return func
 
     # -- statements ------------------------------------------------------------------------

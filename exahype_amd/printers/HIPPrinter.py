@@ -97,6 +97,8 @@ class HIPPrinter(CodePrinter):
             raise ValueError("unknown scheme %r" % scheme)
         self.scheme = scheme
         if pde is None:
+            pde = self._pde_from_bodies(k)
+        if pde is None:
             pde = "euler_ref2d" if (scheme != "aderdg" and k.dim == 2) else "euler"
         self.user_pde = None
         if hasattr(pde, "register") and hasattr(pde, "source"):      # a SympyPDE: compiled for the device on compile()
@@ -174,6 +176,19 @@ class HIPPrinter(CodePrinter):
         return "\n".join(L) + "\n"
 
     # -- execution ----------------------------------------------------------------------------------
+    @staticmethod
+    def _pde_from_bodies(k):
+        """SymPy bodies given with `kernel.function(..., body=...)` for the flux and the eigenvalue -> a SympyPDE."""
+        bodies = getattr(k, "function_bodies", {})
+        flux = next((bodies[n] for n in bodies if n.lower() == "flux"), None)
+        eig = next((bodies[n] for n in bodies if n.lower() in ("maxeigenvalue", "max_eigenvalue")), None)
+        if flux is None and eig is None:
+            return None
+        if flux is None or eig is None:
+            raise ValueError("SymPy bodies are needed for both the flux and the eigenvalue function (got one)")
+        from ..pde_codegen import SympyPDE
+        return SympyPDE(k.n_real, flux=flux, max_eigenvalue=eig, max_dim=k.dim)
+
     def compile(self):
         """Bind libexahype_hip.so (built with hipcc if missing) and create the plan.  Raises without a GPU."""
         from .. import solvers

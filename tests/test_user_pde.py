@@ -152,3 +152,54 @@ def test_euler_from_sympy_equals_builtin_euler():
         Fa, la = exa.pde_eval(exa.PDE_EULER, d, Q)
         Fb, lb = exa.pde_eval(p.register(), d, Q)
         assert np.max(np.abs(Fa - Fb)) < 1e-13 and np.max(np.abs(la - lb)) < 1e-13
+
+
+def _swe_kernel(n_patches, patch_size=4, halo_size=0):
+    """The same shallow-water terms handed over through the operator surface: kernel.function(..., body=...)."""
+    from exahype_amd import KernelBuilder
+    p = swe()
+    k = KernelBuilder(dim=2, patch_size=patch_size, halo_size=halo_size, n_real=3, n_aux=0, n_patches=n_patches)
+    k.item('u')
+    k.function('Flux', parameter_types=['double*', 'int', 'double*'], return_type='void',
+               body=lambda q, d: p.flux_exprs[d] if q == p.q else [e.subs(dict(zip(p.q, q))) for e in p.flux_exprs[d]])
+    k.function('maxEigenvalue', parameter_types=['double*', 'int'], return_type='double',
+               body=lambda q, d: p.eig_exprs[d].subs(dict(zip(p.q, q))))
+    return k, p
+
+
+def test_function_bodies_reach_the_printer_without_gpu():
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import HIPPrinter
+    k, p = _swe_kernel(6)
+    hp = HIPPrinter(k, scheme="aderdg", grid=(3, 2))
+    assert hp.user_pde is not None and hp.user_pde.n_vars == 3
+    body = lambda src: src.split("\n", 1)[1]            # (the first line carries the term set's name)
+    assert body(hp.user_pde.source()) == body(swe().source())   # same expressions -> same device code as the SympyPDE route
+    # a body for one of the two terms only is an error; no bodies: the built-in term sets as before
+    k2 = KernelBuilder(dim=2, patch_size=4, halo_size=0, n_real=3, n_aux=0, n_patches=6)
+    k2.item('u')
+    k2.function('Flux', body=lambda q, d: [q[0]] * 3)
+    with pytest.raises(ValueError):
+        HIPPrinter(k2, scheme="aderdg", grid=(3, 2))
+    with pytest.raises(TypeError):
+        k2.function('maxEigenvalue', body=3.0)
+
+
+@pytest.mark.gpu
+def test_function_bodies_run_like_the_sympy_pde():
+    from exahype_amd.printers import HIPPrinter
+    N, grid = 4, (3, 2)
+    k, p = _swe_kernel(6, patch_size=N)
+    rng = np.random.default_rng(3)
+    u = np.empty(grid + (N, N, 3))
+    u[..., 0] = 1.0 + 0.2 * rng.random(grid + (N, N))
+    u[..., 1:] = 0.1 * (rng.random(grid + (N, N, 2)) - 0.5)
+    dx = (1.0 / 3, 0.5)
+    a = u.copy()
+    HIPPrinter(k, scheme="aderdg", grid=grid).run(a, 1e-3, dx=dx, steps=2)
+    from exahype_amd import KernelBuilder
+    k0 = KernelBuilder(dim=2, patch_size=N, halo_size=0, n_real=3, n_aux=0, n_patches=6)
+    k0.item('u')
+    b = u.copy()
+    HIPPrinter(k0, scheme="aderdg", grid=grid, pde=swe()).run(b, 1e-3, dx=dx, steps=2)
+    assert np.array_equal(a, b) and not np.array_equal(a, u)
