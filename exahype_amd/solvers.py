@@ -470,6 +470,50 @@ class SubcellLimiter:
         check(self.s.lib.exa_lim_operators(self.s._plan, P.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p)))
         return P, R
 
+    def detect(self, dmp_tol=0.5, floor=1e-12):
+        """A-priori troubled-cell indicator on the current state (positivity + a relaxed discrete maximum
+        principle): a cell is troubled if density or pressure is non-positive / not finite at a node, or if the nodal
+        density leaves the range of the cell means of its face neighbourhood by more than dmp_tol times that range.
+        Euler variables (rho, m, E) with gamma = 1.4.  Returns a bool tensor [nc0, nc1, (nc2)] on the device.
+        Host-level logic in torch ops -- the kernels take the mask as an input."""
+        torch = _torch()
+        s = self.s
+        dim = s.dim
+        u = s.u
+        nodes = tuple(range(dim, 2 * dim))
+        rho = u[..., 0]
+        ke = sum(u[..., 1 + a] ** 2 for a in range(min(3, s.nv - 2)))
+        p = 0.4 * (u[..., s.nv - 1] - 0.5 * ke / rho)
+        bad = (rho.amin(nodes) <= floor) | (p.amin(nodes) <= floor) | ~torch.isfinite(u).all(-1).flatten(dim).all(-1)
+        w = torch.as_tensor(s.operators()["w"], device=u.device)
+        mean = rho
+        for _ in range(dim):
+            mean = torch.tensordot(mean, w, dims=([dim], [0]))     # contracts the first remaining node axis
+        lo, hi = mean.clone(), mean.clone()
+        ghost = None
+        if s.halo is not None:                                   # neighbour means across block faces
+            hx = self.hx_mask
+            nc3 = s.nc + [1] * (3 - dim)
+            m3 = mean.reshape(nc3)
+            for d in range(dim):
+                if s.part.partitioned(d):
+                    hx.send[d * 2 + 0].copy_(m3.select(d, 0).reshape(-1, 1))
+                    hx.send[d * 2 + 1].copy_(m3.select(d, nc3[d] - 1).reshape(-1, 1))
+            hx.start()
+            hx.finish()
+            ghost = hx.ghost
+        for d in range(dim):
+            up, dn = mean.roll(-1, d), mean.roll(1, d)
+            if ghost is not None and s.part.partitioned(d):
+                other = [s.nc[a] for a in range(dim) if a != d]
+                up.select(d, s.nc[d] - 1).copy_(ghost[d * 2 + 1].reshape(other))
+                dn.select(d, 0).copy_(ghost[d * 2 + 0].reshape(other))
+            lo = torch.minimum(lo, torch.minimum(up, dn))
+            hi = torch.maximum(hi, torch.maximum(up, dn))
+        span = (hi - lo).clamp_min(floor)
+        bad |= (rho.amax(nodes) > hi + dmp_tol * span) | (rho.amin(nodes) < lo - dmp_tol * span)
+        return bad
+
     def _exchange_subcell_layers(self, m):
         """m: troubled flags of the block, float64 [nc0, nc1, nc2] on the device.  Returns the ghost-layer pointer array."""
         s, hm, hl = self.s, self.hx_mask, self.hx_layer

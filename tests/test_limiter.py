@@ -86,3 +86,42 @@ def test_projection_then_reconstruction_is_identity_p7_3d():
     assert rel_err(pt[0, 1:-1, 1:-1, 1:-1], proj[0, 0, 0]) < 1e-12
     assert rel_err(pt[0, 0, 1:-1, 1:-1], proj[1, 0, 0][14]) < 1e-12
     assert rel_err(pt[0, 1:-1, 1:-1, 16], proj[0, 0, 1][:, :, 0]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_troubled_cell_indicator():
+    """Positivity + relaxed DMP: a smooth state is clean, a density jump / a negative pressure / an oscillation is flagged."""
+    import torch
+    from exahype_amd import solvers as exa
+    dim, N, nc = 2, 4, (8, 6)
+    ops = operators(N)
+    xs = A.node_coords(nc, N, ops)
+    u = np.zeros(nc + (N, N, 5))
+    u[..., 0] = 1.0 + 0.1 * np.sin(2 * np.pi * xs[0]) * np.cos(2 * np.pi * xs[1])
+    u[..., 1] = 0.3 * u[..., 0]
+    u[..., 4] = 2.5 + 0.5 * 0.09 * u[..., 0]
+    s = exa.AderDgSolver(dim, N, nc)
+    lim = exa.SubcellLimiter(s)
+    s.upload(u)
+    assert not bool(lim.detect().any())
+    v = u.copy()
+    v[3, 2, 1, 2, 0] *= 1.8                                     # one node overshoots: that cell (its raised mean may
+    s.upload(v)                                                 # narrow the admissible range of a face neighbour too)
+    m = lim.detect().cpu().numpy()
+    assert m[3, 2] and all(abs(i - 3) + abs(j - 2) <= 1 for i, j in np.argwhere(m))
+    v = u.copy()
+    v[5, 1, ..., 4] = 0.01                                      # negative pressure in one cell
+    s.upload(v)
+    m = lim.detect().cpu().numpy()
+    assert m[5, 1] and m.sum() == 1
+    v = u.copy()
+    v[:4, ..., 0] = 1.0
+    v[4:, ..., 0] = 0.125                                       # Sod-like jump between cells 3|4 (and the periodic wrap 7|0): smooth inside cells
+    s.upload(v)
+    m = lim.detect(dmp_tol=0.5).cpu().numpy()
+    assert not m.any()                                          # piecewise constant data respects the DMP of the means
+    v[4, :, 0, :, 0] = 0.6                                      # a Gibbs-like intermediate layer inside the cell at the jump ... is within range
+    v[4, :, 1, :, 0] = -0.05                                    # ... an undershoot is not
+    s.upload(v)
+    m = lim.detect().cpu().numpy()
+    assert m[4].all() and m.sum() == nc[1]
