@@ -295,3 +295,33 @@ def test_dg_fused_single_stage_step_vs_oracle(exa, orc, N, nc):
     # not offered where it does not apply
     assert not exa.AderDgSolver(2, N, nc, dx=dx, fused_single_stage=True)._fused
     assert not exa.AderDgSolver(3, 3, (2, 2, 2), n_picard=0, fused_single_stage=True)._fused
+
+
+@pytest.mark.parametrize("p,meshes", [(2, (16, 32)), (3, (3, 6)), (5, (2, 4))])
+def test_dg_order_of_accuracy_euler_density_wave_3d(exa, p, meshes):
+    """KAT A.5-6 on the production kernels, against the ANALYTIC solution (independent of the oracle): the smooth Euler
+    density wave rho = 1 + 0.2 sin(2 pi (x+y+z - 3t)), u = (1,1,1), p = 1 is pure advection; L2 error order >= p + 0.7."""
+    from oracle import aderdg_numpy as A
+    d, N = 3, p + 1
+    ops = _ops(N)
+    errs = []
+    for nc in meshes:
+        xs = A.node_coords((nc,) * d, N, ops)
+
+        def exact(t):
+            rho = 1 + 0.2 * np.sin(2 * np.pi * (xs[0] + xs[1] + xs[2] - d * t))
+            q = np.zeros(rho.shape + (5,))
+            q[..., 0] = rho
+            for a in range(3):
+                q[..., 1 + a] = rho
+            q[..., 4] = 1 / 0.4 + 0.5 * rho * d
+            return q
+        s = exa.AderDgSolver(d, N, (nc,) * d)
+        s.upload(exact(0.0))
+        T = 0.04
+        s.run(T, cfl=0.3)
+        w = ops["w"]
+        err2 = np.einsum("abcijk,i,j,k->", (s.download() - exact(T))[..., 0] ** 2, w, w, w) / nc ** d
+        errs.append(np.sqrt(err2))
+    order = np.log2(errs[0] / errs[1])
+    assert order >= p + 0.7, (errs, order)
