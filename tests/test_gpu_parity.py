@@ -297,7 +297,7 @@ def test_dg_fused_single_stage_step_vs_oracle(exa, orc, N, nc):
     assert not exa.AderDgSolver(3, 3, (2, 2, 2), n_picard=0, fused_single_stage=True)._fused
 
 
-@pytest.mark.parametrize("p,meshes", [(2, (16, 32)), (3, (3, 6)), (5, (2, 4))])
+@pytest.mark.parametrize("p,meshes", [(2, (16, 32)), (3, (3, 6)), (5, (2, 4)), (7, (2, 4))])
 def test_dg_order_of_accuracy_euler_density_wave_3d(exa, p, meshes):
     """KAT A.5-6 on the production kernels, against the ANALYTIC solution (independent of the oracle): the smooth Euler
     density wave rho = 1 + 0.2 sin(2 pi (x+y+z - 3t)), u = (1,1,1), p = 1 is pure advection; L2 error order >= p + 0.7."""
