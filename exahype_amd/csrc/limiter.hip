@@ -103,7 +103,8 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
                 __syncthreads();
                 int e2[3] = {N, N, N};
                 double *s2 = A, *d2 = B;
-                for (int b = 0; b < DIM; b++) {
+                for (int bb = 0; bb < DIM; bb++) {
+                    const int b = (a + bb) % DIM;                // normal axis first: the other passes see one layer only
                     if (b == a) lim_apply(P, N, side ? 0 : Ns - 1, 1, N, s2, d2, DIM, e2, b);     // the adjacent layer only
                     else lim_apply(P, N, 0, Ns, N, s2, d2, DIM, e2, b);
                     e2[b] = (b == a) ? 1 : Ns;
@@ -151,7 +152,8 @@ limiter_face_layers_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, 
         __syncthreads();
         int e[3] = {N, N, N};
         double *src = A, *dst = B;
-        for (int b = 0; b < DIM; b++) {
+        for (int bb = 0; bb < DIM; bb++) {
+            const int b = (a + bb) % DIM;                        // normal axis first
             if (b == a) lim_apply(P, N, side ? Ns - 1 : 0, 1, N, src, dst, DIM, e, b);     // the layer at the face only
             else lim_apply(P, N, 0, Ns, N, src, dst, DIM, e, b);
             e[b] = (b == a) ? 1 : Ns;
