@@ -5,20 +5,21 @@
 // "Level-streamed" Picard loop.  The derivative sums S_l = sum_d (1/dx_d) D_d f_d(q_l) of a time level l
 // need only q_l, and the time update q_l' = u - dt sum_l T[l'][l] S_l is linear in them.  So an iteration
 // walks over the time levels two at a time:
-//   load    q_l of the two levels from the workgroup's slab (L2/MALL-resident), flux scalars once per node -> LDS
-//   derive  the three directions at once on 12 waves, pencil tasks split by rows (two half tasks per pencil
-//           keep the partial sums at 40 VGPRs):  y -> A, z -> B, x holds and stores over Q after the barrier
-//   fold    node owners (node, half of the output levels) add T[l'][l] * (S_x + S_y + S_z) into register
-//           accumulators -- the output-stationary form of the time contraction
+//   load    q_l of the two levels (node owners), flux scalars once per node -> LDS
+//   derive  the three directions at once, one pencil per lane, even-odd form of D:  y -> A, z -> B, x holds and
+//           stores over Q after the barrier
+//   fold    node owners add T[l'][l] * (S_x + S_y + S_z) into register accumulators for their output levels --
+//           the output-stationary form of the time contraction
 // and ends with q_l' = u - dt * acc, written back to the slab (the last iteration keeps it in registers for
 // the time averages).  A step takes the levels g and LH + g, so that the lane that loads a level is the lane
 // that produced it: slab traffic is lane-private (no fence), fetched one step ahead of its use, and the first
 // level of each half never leaves the registers.  Per iteration and cell that is 3/4 of q written and read
-// (120 KiB each way at N = 8) instead of every partial sum (the scratch variant); LDS holds two levels, not eight.
+// (120 KiB each way at N = 8) instead of every partial sum (the first, all-in-global-memory version); LDS holds two
+// levels, not eight.
 //
 // LDS strides: odd row stride (N = 8: 9) and plane stride = 8 mod 32 doubles keep the y and z pencils
-// conflict-free for 32-lane ds_read_b64 groups (scripts/lds_stride_search.py model); x pencils and the
-// node-linear phases pay ~1 extra pass per wave instruction.
+// conflict-free for 32-lane ds_read_b64 groups (scripts/lds_stride_search.py model); an owner-slot -> node permutation
+// (kernel prologue) does the same for the node-linear phases; the x pencils keep a 2-way conflict.
 #pragma once
 #include "exa_dg_kernels.hpp"
 
@@ -72,6 +73,8 @@ template <int N> struct StreamGeo {
 // HS = tasks per pencil in the derive phase (2: row halves, 40 VGPRs of partial sums; 1: whole pencils, 80),
 // OH = owners per node in the load / fold phases (2: each owns half of the output levels; 1: all of them).
 // HS = OH = 2 runs 16 waves at <= 128 VGPRs, HS = OH = 1 runs 8 waves at <= 256 VGPRs and reads each pencil once.
+// The library instantiates HS = OH = 1 (dg_inst.hip); the other values were timed (profiles/r01_stream_kernel.txt) and
+// are outside the parity tests.
 template <int N, class PDE, int HS, int OH> struct StageAStream {
     using G = StreamGeo<N>;
     static constexpr int NV = PDE::NV, NA = PDE::NAUX;
