@@ -8,11 +8,12 @@
 //          (face-wide max eigenvalue) and the surface corrector.
 //
 // Mapping to the machine: CPB cells per workgroup, the whole space-time DoF block
-// of a cell lives in LDS as SoA [var][time slab][padded node] (Geo<>), the 1-D
-// operators arrive in SGPRs through the kernarg segment (DgOps<>), all
-// contractions are sum-factorised pencil products kept in registers
-// (N loads -> N*N fp64 FMAs per variable).  HBM traffic per cell is the
-// compulsory one: u read once, u* written once, traces written once.
+// of a cell lives in LDS as SoA [var][time slab][node] (Geo<>), the 1-D operators
+// live in a plan-owned HBM image (DgOps<> + lane tables) and reach the FMAs as SGPR
+// operands through scalar loads, all contractions are sum-factorised pencil
+// products kept in registers.  HBM traffic per cell is the compulsory one: u read
+// once, u* written once, traces written once.  (3-D cells with N = 7, 8 do not fit
+// the LDS: exa_dg_stream.hpp; the single-stage 2-D step in one launch: exa_dg_fused.hpp.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -124,16 +125,17 @@ template <int DIM, int N, class PDE, int CPB> struct StageA {
 
 // Cell image in LDS: three q-sized arrays Q | A | B, each SoA [var][time slab][node].
 //
-// Thread layout: DIM groups of WPD waves.  In a Picard iteration group d computes the pencils of
-// direction d -- all directions at once, 3 waves per SIMD at N = 6, so one in-order wave's LDS
-// issue/latency hides under the other two (v4, one wave per SIMD: ~6 cycles per VALU and ~8.7 per
-// LDS instruction, serial; dropping every FMA saved 13 % -- profiles/r01_stage_a_stamps.txt).
-// Only plain LDS stores are used for the partial sums (fp64 LDS atomics cost ~17 LDS cycles per
-// wave instruction, v5): y -> A and z -> B directly; x -- the conflict-free, fastest group -- keeps its
-// sums in registers over the barrier and then writes them over Q, which is dead by then.  The time update adds the three, is split by
-// variable between two adjacent lanes, and writes the new iterate back into Q.  The cached scalars
-// of the flux (Euler: 1/rho, p) are recomputed per pencil node instead of stored: VALU has slack,
-// LDS (68 % busy in v5) has not, and the freed 20 KiB are what buys the second sum array.
+// Thread layout: DIM groups of WPD waves, persistent grid (a workgroup walks over cells and prefetches the next
+// cell's u).  In a Picard iteration group d computes the pencils of direction d -- all directions at once, 3 waves per
+// SIMD at N = 6 (v4, one wave per SIMD, ran ~6 cycles per VALU and ~8.7 per LDS instruction back to back;
+// profiles/r01_stage_a_stamps.txt).  Which lane takes which pencil comes from host-built tables (dg_inst.hip
+// OpsImage) that make every LDS wave instruction of the phase bank-conflict-free.  The contraction with D uses its
+// even-odd form (half the FMAs).  Only plain, unpaired LDS stores are used for the partial sums (fp64 LDS atomics cost
+// ~17 LDS cycles per wave instruction, v5; ds_write2_b64 13 cycles for two values against 6 per ds_write_b64):
+// y -> A and z -> B directly; x keeps its sums in registers over the barrier and then writes them over Q, which is dead
+// by then.  The time update adds the three, is split by variable over the DIM groups (all waves), and writes the new
+// iterate back into Q.  The cached scalars of the flux (Euler: 1/rho, p) are recomputed per pencil node instead of
+// stored: the freed 20 KiB are what buys the second sum array.
 template <int DIM, int N, class PDE, int CPB>
 __global__ void __launch_bounds__((StageA<DIM, N, PDE, CPB>::NT))
 dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
