@@ -3,30 +3,67 @@
 (space-time predictor Picard loop + volume integral + face Riemann solve +
 corrector) on 1/2/4/8 MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg1|cfg4|fv-ref]
 
-N = 1 runs BASELINE.json configs[2] (128^3 cells, one GPU).  N > 1 (launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) keeps
-128^3 cells per GPU (weak scaling; N = 8 is configs[3], 256^3 cells) on a
-Cartesian process grid with the RCCL face-trace halo exchange overlapped with
-the interior predictor work.  Synthetic data: smooth Euler
-density wave + seeded 1e-3 noise, fixed dt.  One "step" = one full time step of
-every cell.  Prints ONE JSON line on rank 0.
+--config cfg2 (default, the configuration BASELINE.json's metric is quoted on):
+  N = 1 runs BASELINE.json configs[2] (128^3 cells, one GPU).  N > 1 keeps 128^3 cells per GPU
+  (weak scaling; N = 8 is configs[3], 256^3 cells) on a Cartesian process grid with the RCCL
+  face-trace halo exchange overlapped with the interior predictor work.  `python bench.py --gpus N`
+  starts its N ranks itself (one process per GPU, before the parent touches a GPU); launched under
+  `torch.distributed.run` it uses the ranks it is given.
+--config cfg1 / cfg4 / fv-ref (one GPU each): configs[1] (2-D p=3, 512^2, single-stage
+  step), configs[4]'s per-GPU shape (p=7, 64^3 cells + FV subcell limiter, 5 % troubled), and the
+  reference-native FV Rusanov patch update (2-D, P=4, H=1, 5+5 variables, 2^20 patches).
+
+Synthetic data: smooth Euler density wave + seeded 1e-3 noise, fixed dt.  One "step" =
+one full time step of every cell.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet: fp64 vector == fp64 matrix (MFMA) peak; DESIGN.md "Roofs"
+FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet: fp64 vector peak (== the fp64 matrix peak); DESIGN.md "Roofs"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0   # ... and its measured float4-copy rate
 
 
+# ------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher
+# ------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start n worker processes (one rank each) and relay rank 0's output.  The parent never initialises a GPU (no
+    torch.cuda call, no HIP call): it only starts children and waits -- nothing is exec'ed over a GPU process."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
+        sys.exit(1)
+    sys.exit(0)
+
+
+# ------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ------------------------------------------------------------------------------------------------------
 def synthetic_state(solver, part_coords, pdims, seed):
     """Density wave rho = 1 + 0.2 sin(2 pi sum x), u = (1,1,1), p = 1, times 1 + 1e-3 U(-1,1); built on the device."""
     import torch
@@ -52,71 +89,133 @@ def synthetic_state(solver, part_coords, pdims, seed):
     return 1.0 + (1.4 * 1.0 / 0.8) ** 0.5          # |u_d| + c_s upper bound per direction
 
 
-def cpu_baseline(N, n_it, seconds=12.0):
-    """The oracle (oracle/exa_oracle.c, OpenMP over cells) on the host cores, same kernel stack, bounded sample."""
+# ------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, timed on the GPU box's host cores; reported, never the target)
+# ------------------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """(cpus this process may use, physical cores of the machine, model name)."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    try:                                                     # a cgroup CPU quota bounds what the threads really get
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            usable = max(1, min(usable, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return usable, (len(phys) or (os.cpu_count() or 1)), model
+
+
+def cpu_threads():
+    usable, phys, _ = host_cpu_info()
+    return int(os.environ.get("OMP_NUM_THREADS", max(1, min(usable, phys))))
+
+
+def cpu_baseline_dg(dim, N, n_it, seconds=12.0):
+    """The oracle (oracle/exa_oracle.c, OpenMP over cells) on the host cores: the same ADER-DG step on a bounded block,
+    >= 16 cells per thread, work arrays allocated once outside the timed steps."""
     import numpy as np
+    threads = cpu_threads()
     import oracle
     from oracle.dg_operators import operators
     from tests.util import euler_dg_state
-    oracle.lib()
-    nc = (12, 12, 12)
+    oracle.lib().orc_set_threads(threads)
+    threads = oracle.lib().orc_get_max_threads()
+    n = 4
+    while n ** dim < 16 * threads:
+        n += 2
+    nc = (n,) * dim
     ops = operators(N)
-    u = euler_dg_state(nc + (N, N, N), seed=2, amp=0.1).reshape(-1)
+    u = np.ascontiguousarray(euler_dg_state(nc + (N,) * dim, seed=2, amp=0.1)).reshape(-1)
     dx = [1.0 / c for c in nc]
-    dt = 1e-4
-    u = oracle.aderdg_step(u, dt, dx, ops, 3, N, 5, oracle.PDE_EULER, n_it, nc)     # warm-up
-    t0, steps = time.perf_counter(), 0
+    dt = 1e-4 / N
+    for _ in range(2):                                                                # warm-up (pages touched, team started)
+        t0 = time.perf_counter()
+        oracle.aderdg_run(u, dt, dx, ops, dim, N, 5, oracle.PDE_EULER, n_it, nc, 1)
+        one = time.perf_counter() - t0
+    chunk = int(max(1, min(500, 1.0 / max(one, 1e-6))))                                # ~1 s of steps per call, arrays allocated once per call
+    steps, t0 = 0, time.perf_counter()
     while True:
-        u = oracle.aderdg_step(u, dt, dx, ops, 3, N, 5, oracle.PDE_EULER, n_it, nc)
-        steps += 1
+        oracle.aderdg_run(u, dt, dx, ops, dim, N, 5, oracle.PDE_EULER, n_it, nc, chunk)
+        steps += chunk
         el = time.perf_counter() - t0
-        if el >= seconds or steps >= 400:
+        if el >= seconds:
             break
-    dof = int(np.prod(nc)) * N ** 3 * 5
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    usable, phys, model = host_cpu_info()
+    dof = int(np.prod(nc)) * N ** dim * 5
     return {"value": dof * steps / el, "unit": "DoF-updates/s", "cores": threads, "kind": "port",
-            "sample": "%d steps of a %dx%dx%d-cell block, same p=%d Euler ADER-DG step, oracle/exa_oracle.c "
-                      "(gcc -O3 -fopenmp), %.1f s" % (steps, nc[0], nc[1], nc[2], N - 1, el)}
+            "sample": "%d steps of a %s-cell block (%d cells per thread), same p=%d Euler ADER-DG step (%d Picard iterations), "
+                      "oracle/exa_oracle.c (gcc -O3 -fopenmp), %.1f s" % (steps, "x".join(map(str, nc)), int(np.prod(nc)) // threads,
+                                                                          N - 1, n_it, el),
+            "host": {"cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "nproc": os.cpu_count()}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cells", type=int, default=128, help="cells per axis per GPU (default: BASELINE configs[2])")
-    ap.add_argument("--order", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path with host-staged exchange")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    a = ap.parse_args()
+def cpu_reference_fv(seconds=6.0):
+    """Where the reference is today: its generated `time_step` (Unit test/test.cpp, compiled where it lies
+    into oracle/_ref) on ONE core, 2-D 4x4 patch, 5+5 variables, back-to-back calls over independent patches -- or,
+    when oracle/_ref did not travel, the statement-for-statement restatement (oracle.fv_faithful)."""
+    import numpy as np
+    import oracle
+    n = 1 << 14
+    Q = np.ascontiguousarray(np.tile(2.0 + np.sin(3.141 * np.arange(360) / 360), (n, 1)))
+    R = oracle.ref()
+    if R is not None:
+        def call():
+            R.ref_time_step_batched(Q.ravel(), 1e-3, n, 360)
+        kind, what = "reference", "Unit test/test.cpp + Functions.cpp (g++ -O2, oracle/_ref)"
+    else:
+        oracle.lib().orc_set_threads(1)
 
-    import torch
+        def call():
+            oracle.lib().orc_fv_rusanov_faithful(Q.ravel(), 1e-3, 2, 4, 1, 5, 5, n, oracle.PDE_EULER_REF2D)
+        kind, what = "port", "oracle/exa_oracle.c faithful restatement (gcc -O3), 1 thread"
+    call()
+    t0, reps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        call()
+        reps += 1
+    el = time.perf_counter() - t0
+    return {"value": n * reps * 16 * 5 / el, "unit": "DoF-updates/s", "volume_updates_per_s": n * reps * 16 / el, "cores": 1,
+            "kind": kind, "sample": "%d calls of time_step on 4x4 patches (5+5 variables), %s, %.1f s" % (n * reps, what, el)}
+
+
+def read_traffic(name, **match):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh writes profiles/<name>;
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  Not measured inside this run: `traffic_source` says where from."""
+    tf = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(tf):
+        rec = json.load(open(tf))
+        if all(rec.get(k) == v for k, v in match.items()):
+            return rec.get("hbm_bytes_per_launch"), "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# configurations
+# ------------------------------------------------------------------------------------------------------
+def run_cfg2(a, torch, exa, world, rank, local):
+    """BASELINE configs[2] / configs[3]: 3-D Euler p=5, full predictor + corrector, 128^3 cells per GPU."""
     import torch.distributed as dist
-    from exahype_amd import solvers as exa
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (no CPU fallback in the product path)")
-    if a.share_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    part = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(a.backend)
-        part = exa.CartesianPartition(world, rank, 3)
+    part = exa.CartesianPartition(world, rank, 3) if world > 1 else None
     pdims = part.pdims if part else [1, 1, 1]
     coords = part.coords if part else [0, 0, 0]
-
     N = a.order + 1
     nc = [a.cells] * 3
     dx = [1.0 / (nc[d] * pdims[d]) for d in range(3)]
@@ -135,18 +234,12 @@ def main():
     for _ in range(a.warmup):
         s.step(dt)
     sync()
-    # stage-A launch durations, measured live with events on the stream the kernels are launched on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    s.stage_a_events = []                  # stage-A launch durations: events on the stream the kernels are launched on
+    if world > 1:
+        s.exchange_events = []
     t0 = time.perf_counter()
-    if world == 1:
-        for k in range(a.steps):
-            ev[k][0].record()
-            s.predictor_volume(dt)
-            ev[k][1].record()
-            s.riemann_corrector(dt)
-    else:
-        for k in range(a.steps):
-            s.step(dt)
+    for _ in range(a.steps):
+        s.step(dt)
     sync()
     el = time.perf_counter() - t0
     if world > 1:
@@ -154,12 +247,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     finite = bool(torch.isfinite(s.u).all().item())
-
     dof_per_gpu = nc[0] * nc[1] * nc[2] * N ** 3 * 5
-    value = dof_per_gpu * world * a.steps / el
     out = {
         "metric": "DoF-updates/sec, 3D Euler p=%d fused STP+volume+Riemann, 1/2/4/8 MI355X" % a.order,
-        "value": value, "unit": "DoF-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": dof_per_gpu * world * a.steps / el, "unit": "DoF-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "3D compressible Euler, ADER-DG p=%d, %d^3 cells per GPU (%dx%dx%d process grid), "
@@ -168,23 +259,215 @@ def main():
                    "parallelism": "cartesian-%dx%dx%d" % tuple(pdims)},
         "finite": finite,
     }
+    # stage A: per step one launch (single GPU) or the shell boxes + the interior box (sharded); sum per step
+    per_step = len(s.stage_a_events) // a.steps
+    ta = sum(e0.elapsed_time(e1) for e0, e1 in s.stage_a_events) / a.steps * 1e-3
     if world == 1:
-        ta = sum(e0.elapsed_time(e1) for e0, e1 in ev) / a.steps * 1e-3       # s per stage-A launch
         ach = work["flop_a"] / ta / 1e12
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "stage_a_traffic.json")
-        if os.path.exists(tf):
-            rec = json.load(open(tf))
-            if rec.get("cells") == a.cells and rec.get("order") == a.order:
-                traffic = rec.get("hbm_bytes_per_launch")
-        out["roofline"] = {"kernel": "dg_stage_a_kernel<3,%d,Euler>" % N, "bound": "mfma", "achieved": ach,
+        traffic, src = read_traffic("stage_a_traffic.json", cells=a.cells, order=a.order)
+        out["roofline"] = {"kernel": "dg_stage_a_kernel<3,%d,Euler>" % N, "bound": "fp64-valu", "achieved": ach,
                            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
-                           "launch_ms": ta * 1e3, "flop_per_launch": work["flop_a"],
+                           "traffic_source": src, "launch_ms": ta * 1e3, "launches_per_step": per_step, "flop_per_launch": work["flop_a"],
                            "hbm_achieved_gbs": work["bytes_a"] / ta / 1e9, "hbm_frac": work["bytes_a"] / ta / 1e9 / HBM_PEAK_GBS,
                            "hbm_frac_of_measured_copy": work["bytes_a"] / ta / 1e9 / HBM_MEASURED_GBS,
-                           "note": "fp64: MFMA peak == vector peak = 78.6 TFLOP/s on MI355X; the kernel is fp64-compute-bound (48 FLOP/B)"}
+                           "note": "fp64-compute-bound (48 FLOP/B): priced against the 78.6 TFLOP/s fp64 vector peak; the kernel "
+                                   "issues no MFMA (fp64 MFMA has the same peak and fills 28 % of a tile at N = 6)"}
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, N)
+            out["cpu_baseline"] = cpu_baseline_dg(3, N, N)
+            out["cpu_reference_fv"] = cpu_reference_fv()
+    else:
+        # the exchange (pack + RCCL send/recv) on the comm stream against the interior stage A on the compute stream
+        ex, ov = [], []
+        for ready, c0, c1, i0, i1 in s.exchange_events:
+            cs, ce = ready.elapsed_time(c0), ready.elapsed_time(c1)
+            is_, ie = ready.elapsed_time(i0), ready.elapsed_time(i1)
+            ex.append(ce - cs)
+            ov.append(max(0.0, min(ce, ie) - max(cs, is_)) / max(ce - cs, 1e-9))
+        mine = torch.tensor([sum(ex) / len(ex), sum(ov) / len(ov), ta * 1e3], dtype=torch.float64,
+                            device="cuda" if a.backend == "nccl" else "cpu")
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        names = [None] * world
+        dist.all_gather_object(names, "%s:%d" % (torch.cuda.get_device_name(local), local))
+        out["rccl_ranks"] = dist.get_world_size()
+        out["backend"] = dist.get_backend()
+        out["devices"] = names
+        out["exchange_ms"] = max(float(v[0]) for v in allv)
+        out["overlap_frac"] = min(float(v[1]) for v in allv)
+        out["stage_a_ms"] = max(float(v[2]) for v in allv)
+    return out
+
+
+def run_cfg1(a, torch, exa, local):
+    """BASELINE configs[1]: 2-D Euler p=3, 512 x 512 cells, volume + Riemann + corrector only (single stage), one fused launch."""
+    N, nc = 4, (512, 512)
+    s = exa.AderDgSolver(2, N, nc, n_picard=0, fused_single_stage=True, device=local)
+    lam = synthetic_state(s, [0, 0, 0], [1, 1, 1], seed=1)
+    dt = 0.1 * min(s.dx) / ((2 * 3 + 1) * 2 * lam)
+    steps, warm = max(a.steps, 20), max(a.warmup, 5)
+    for _ in range(warm):
+        s.step(dt)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        s.step(dt)
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tk = e0.elapsed_time(e1) / steps * 1e-3
+    dof = nc[0] * nc[1] * N * N * 5
+    b_alg = 8 * 5 * (2 * N ** 2 + 8 * 2 * N) * nc[0] * nc[1]            # SURVEY.md 8(d): 3 840 B per cell
+    traffic, src = read_traffic("r02_traffic_cfg1.json")
+    out = {"metric": "DoF-updates/sec, 2D Euler p=3 volume+Riemann+corrector (single stage), 1 MI355X", "value": dof * steps / el,
+           "unit": "DoF-updates/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: 2D compressible Euler, ADER-DG p=3, 512x512 cells, volume + Riemann + corrector "
+                                  "(n_picard = 0), fused single launch", "cells_per_gpu": nc[0] * nc[1], "order": 3, "n_vars": 5, "dt": dt},
+           "finite": bool(torch.isfinite(s.u).all().item()),
+           "roofline": {"kernel": "dg_fused_single_kernel<4,Euler>", "bound": "hbm", "achieved": b_alg / tk / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": b_alg / tk / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": b_alg / tk / 1e9 / HBM_MEASURED_GBS,
+                        "traffic": traffic, "traffic_source": src, "launch_ms": tk * 1e3, "bytes_per_launch": b_alg}}
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_dg(2, N, 0, seconds=6.0)
+    return out
+
+
+def run_cfg4(a, torch, exa, local):
+    """BASELINE configs[4], the per-GPU shape on one GPU: 3-D Euler p=7, 64^3 cells, FV subcell limiter with a Bernoulli(0.05)
+    troubled mask (seed 4): troubled cells take the 15^3 FV Rusanov patch update instead of the DG result."""
+    N, n = 8, a.cells if a.cells != 128 else 64
+    s = exa.AderDgSolver(3, N, (n,) * 3, device=local)
+    lam = synthetic_state(s, [0, 0, 0], [1, 1, 1], seed=4)
+    dt = 0.1 * min(s.dx) / ((2 * 7 + 1) * 3 * lam)
+    g = torch.Generator(device=s.dev)
+    g.manual_seed(4)
+    mask = torch.rand((n,) * 3, generator=g, device=s.dev) < 0.05
+    lim = exa.SubcellLimiter(s, capacity=int(0.08 * n ** 3) + 16)
+    steps, warm = a.steps, max(1, a.warmup)
+    for _ in range(warm):
+        cnt = lim.step(dt, mask)
+    torch.cuda.synchronize()
+    lim.check(wait=True)
+    s.stage_a_events = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lim.step(dt, mask)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ta = sum(e0.elapsed_time(e1) for e0, e1 in s.stage_a_events) / steps * 1e-3
+    work = s.work()
+    dof = n ** 3 * N ** 3 * 5
+    traffic, src = read_traffic("r02_traffic_cfg4.json", cells=n)
+    out = {"metric": "DoF-updates/sec, 3D Euler p=7 ADER-DG + FV subcell limiter, 1 MI355X", "value": dof * steps / el, "unit": "DoF-updates/s",
+           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4] per-GPU shape: 3D compressible Euler, ADER-DG p=7, %d^3 cells, 8 Picard iterations + "
+                                  "volume + Riemann + corrector, FV subcell limiter (15^3 patches) on a Bernoulli(0.05) troubled mask" % n,
+                      "cells_per_gpu": n ** 3, "order": 7, "n_vars": 5, "dt": dt, "troubled_cells": int(cnt)},
+           "finite": bool(torch.isfinite(s.u).all().item()),
+           "roofline": {"kernel": "dg_stage_a_stream_kernel<8,Euler>", "bound": "fp64-valu", "achieved": work["flop_a"] / ta / 1e12,
+                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": work["flop_a"] / ta / 1e12 / FP64_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_source": src, "launch_ms": ta * 1e3, "flop_per_launch": work["flop_a"],
+                        "algorithmic_bytes_per_launch": work["bytes_a"]}}
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_dg(3, N, N, seconds=10.0)
+    return out
+
+
+def run_fv_ref(a, torch, exa, local):
+    """SURVEY.md 8(d) FV-parity row, batched: the reference's own configuration (2-D, P=4, H=1, 5+5 variables; Batched_stateless.py:9),
+    2^20 patches, faithful mode (bit-exact with the compiled reference)."""
+    P, H, m, aux, n = 4, 1, 5, 5, 1 << 20
+    S, V = P + 2 * H, m + aux
+    k = exa.FVRusanovKernel(2, P, H, m, aux, n, exa.PDE_EULER_REF2D, exa.FV_FAITHFUL, device=local)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    Q = torch.rand((n, S, S, V), generator=g, device="cuda", dtype=torch.float64)
+    Q[..., 0] += 1.0
+    Q[..., 3] += 3.0
+    steps, warm = max(a.steps, 20), max(a.warmup, 3)
+    for _ in range(warm):
+        k.time_step(Q, 1e-4, 0.1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        k.time_step(Q, 1e-4, 0.1)
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tk = e0.elapsed_time(e1) / steps * 1e-3
+    vols = n * P * P
+    b_alg = vols * (8 * V * (S / P) ** 2 + 8 * m)                       # patch + halo read once, n_real written once (220 B per volume)
+    traffic, src = read_traffic("r02_traffic_fv_ref.json")
+    out = {"metric": "DoF-updates/sec, FV Rusanov patch update (reference configuration 2D P=4 H=1 5+5 vars), 1 MI355X",
+           "value": vols * m * steps / el, "unit": "DoF-updates/s", "volume_updates_per_s": vols * steps / el, "n_gpus": 1, "steps": steps,
+           "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": "reference-native FV Rusanov time_step (Unit test/test.cpp shape): 2D, patch 4x4, halo 1, 5+5 variables, "
+                                  "2^20 patches, faithful mode (bit-exact with the compiled reference)", "patches": n},
+           "finite": bool(torch.isfinite(Q).all().item()),
+           "roofline": {"kernel": "fv_rusanov_kernel<2,EulerRef2D,faithful,staged,4x4>", "bound": "hbm", "achieved": b_alg / tk / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_alg / tk / 1e9 / HBM_PEAK_GBS,
+                        "frac_of_measured_copy": b_alg / tk / 1e9 / HBM_MEASURED_GBS, "traffic": traffic, "traffic_source": src,
+                        "launch_ms": tk * 1e3, "bytes_per_launch": b_alg}}
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_reference_fv()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg1", "cfg4", "fv-ref"])
+    ap.add_argument("--cells", type=int, default=128, help="cells per axis per GPU (default: BASELINE configs[2])")
+    ap.add_argument("--order", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path with host-staged exchange")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if a.config != "cfg2":
+            sys.exit("bench.py: --config %s is a single-GPU configuration" % a.config)
+        spawn_ranks(a.gpus, sys.argv[1:])                      # does not return
+    if a.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d" % (a.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    from exahype_amd import solvers as exa
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if a.share_gpu:
+        local = 0
+    elif local >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d has no GPU (%d visible); --share-gpu is for rehearsals only" % (rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
+
+    if a.config == "cfg2":
+        out = run_cfg2(a, torch, exa, world, rank, local)
+    elif a.config == "cfg1":
+        out = run_cfg1(a, torch, exa, local)
+    elif a.config == "cfg4":
+        out = run_cfg4(a, torch, exa, local)
+    else:
+        out = run_fv_ref(a, torch, exa, local)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

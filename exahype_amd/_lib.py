@@ -25,6 +25,7 @@ SIGNATURES = {
     "exa_fv_q_count": (C.c_long, [_vp]),
     "exa_fv_time_step_host": (C.c_int, [_vp, _vp, C.c_double, C.c_double]),
     "exa_fv_time_step_device": (C.c_int, [_vp, _vp, C.c_double, C.c_double, _vp]),
+    "exa_fv_time_step_device_masked": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, _vp]),
     "exa_dg_plan_create": (C.c_int, [C.c_int] * 6 + [_lp, C.POINTER(_vp)]),
     "exa_dg_plan_destroy": (C.c_int, [_vp]),
     "exa_dg_dof_count": (C.c_long, [_vp]),
@@ -70,11 +71,13 @@ def load(build_if_missing=True):
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise ExaHypeHipError(f"{LIB_PATH} is missing (run `python -m exahype_amd.build`); there is no CPU fallback")
-        from . import build as _build
-        _build.build()
+    from . import build as _build
+    if build_if_missing:
+        _build.build()                   # no-op when the library matches the sources (content stamp), else rebuilds
+    elif not os.path.exists(LIB_PATH):
+        raise ExaHypeHipError(f"{LIB_PATH} is missing (run `python -m exahype_amd.build`); there is no CPU fallback")
+    elif not _build.up_to_date():
+        raise ExaHypeHipError(f"{LIB_PATH} is older than its sources (run `python -m exahype_amd.build`)")
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

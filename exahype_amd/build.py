@@ -7,6 +7,7 @@ GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
 """
 import argparse
 import concurrent.futures as cf
+import hashlib
 import os
 import shutil
 import subprocess
@@ -41,12 +42,27 @@ def _hipcc():
     return exe
 
 
-def _sources_mtime():
-    m = 0.0
+STAMP = LIB + ".stamp"
+
+
+def _sources_digest():
+    """Content hash of everything the library is built from (file times do not survive the copy to the GPU box)."""
+    h = hashlib.sha256()
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
-        for f in os.listdir(root):
-            m = max(m, os.path.getmtime(os.path.join(root, f)))
-    return max(m, os.path.getmtime(os.path.abspath(__file__)))
+        for f in sorted(os.listdir(root)):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    h.update(open(os.path.abspath(__file__), "rb").read())
+    h.update((ARCH + " " + os.environ.get("EXA_EXTRA_FLAGS", "")).encode())   # (no absolute paths: the tree moves)
+    return h.hexdigest()
+
+
+def up_to_date():
+    """True if the built library was made from exactly the sources that are in the tree now."""
+    try:
+        return os.path.exists(LIB) and open(STAMP).read().strip() == _sources_digest()
+    except OSError:
+        return False
 
 
 def _compile(unit, verbose):
@@ -63,7 +79,7 @@ def _compile(unit, verbose):
 
 def build(force=False, jobs=None, verbose=False):
     """Compile every unit (in parallel) and link the shared library; returns its path."""
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _sources_mtime():
+    if not force and up_to_date():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -74,6 +90,8 @@ def build(force=False, jobs=None, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    with open(STAMP, "w") as f:
+        f.write(_sources_digest() + "\n")
     return LIB
 
 

@@ -39,15 +39,15 @@ struct UserPde {
     void* handle;
     const DgLaunchTable* dg[4];
     int nv;
-    int (*fv)(int, int, int, int, int, int, long, double*, double, double, void*);
+    int (*fv)(int, int, int, int, int, int, long, double*, double, double, const long*, void*);
     int (*ev)(int, long, int, const double*, double*, double*, void*);
 };
 static std::vector<UserPde> g_user;
 
 int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                   double h, hipStream_t s) {
+                   double h, const long* slot, hipStream_t s) {
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].fv) { set_error("pde %d is not registered", pde); return -1; }
-    return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, (void*)s);
+    return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, (void*)s);
 }
 int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s) {
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].ev) { set_error("pde %d is not registered", pde); return -1; }
@@ -182,12 +182,16 @@ int exa_fv_plan_destroy(exa_fv_plan* plan) { delete plan; return EXA_OK; }
 
 long exa_fv_q_count(const exa_fv_plan* plan) { return plan ? plan->count : 0; }
 
-int exa_fv_time_step_device(exa_fv_plan* p, double* Q_dev, double dt, double h, void* stream) {
-    if (!p || !Q_dev) { set_error("exa_fv_time_step_device: NULL argument"); return EXA_ERR_INVALID; }
+int exa_fv_time_step_device_masked(exa_fv_plan* p, double* Q_dev, const long* slot_dev, double dt, double h, void* stream) {
+    if (!p || (!Q_dev && p->count > 0)) { set_error("exa_fv_time_step_device: NULL argument"); return EXA_ERR_INVALID; }
     if (p->mode == EXA_FV_RUSANOV && !(h > 0.0)) { set_error("EXA_FV_RUSANOV needs the volume size h > 0"); return EXA_ERR_INVALID; }
     int rc = use_device(p->device);
     if (rc) return rc;
-    return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, dt, h, (hipStream_t)stream);
+    return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, dt, h, slot_dev, (hipStream_t)stream);
+}
+
+int exa_fv_time_step_device(exa_fv_plan* p, double* Q_dev, double dt, double h, void* stream) {
+    return exa_fv_time_step_device_masked(p, Q_dev, nullptr, dt, h, stream);
 }
 
 int exa_fv_time_step_host(exa_fv_plan* p, double* Q_host, double dt, double h) {

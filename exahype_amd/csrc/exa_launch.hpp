@@ -51,13 +51,14 @@ struct DgLaunchTable {
 const DgLaunchTable* dg_launch_table(int dim, int pde);
 
 // fv_rusanov.hip
+// slot: nullptr, or one entry per patch (< 0: patch not in use, left untouched)
 int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
-              double h, hipStream_t s);
+              double h, const long* slot, hipStream_t s);
 int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
 
 // user PDE term sets registered at run time (capi.cpp: exa_register_pde), pde ids >= 100
 int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                   double h, hipStream_t s);
+                   double h, const long* slot, hipStream_t s);
 int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
 
 void set_error(const char* fmt, ...);

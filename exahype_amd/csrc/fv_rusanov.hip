@@ -42,7 +42,7 @@ using FvRuntimeShape = FvShape<0, 0, 0, 0>;
 template <int DIM, class PDE, int MODE, int CPT, int NT, bool STAGE, class SHAPE = FvRuntimeShape>
 __global__ void __launch_bounds__(NT)
 fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt, double dt, double dt_over_h, long n_patches,
-                  int ppb) {
+                  int ppb, const long* __restrict__ slot) {
     const int P = SHAPE::P ? SHAPE::P : P_rt, H = SHAPE::P ? SHAPE::H : H_rt;
     const int m = SHAPE::P ? SHAPE::M : m_rt, V = SHAPE::P ? SHAPE::V : V_rt;
     extern __shared__ __attribute__((aligned(16))) double fv_lds[];
@@ -53,7 +53,9 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
     const int ncell = (DIM == 3) ? P * P * P : P * P;
     const int pl = (CPT == 1) ? (int)threadIdx.x / ncell : 0;            // patch slot of this thread
     const long patch = (long)blockIdx.x * ppb + pl;
-    const bool live = pl < ppb && patch < n_patches;
+    // slot (optional): one entry per patch, < 0 = this patch is not in use (exa_fv_time_step_device_masked: the
+    // number of patches in use is known on the device only, the launch covers the array's capacity)
+    const bool live = pl < ppb && patch < n_patches && (!slot || slot[patch] >= 0);
     double* Qg = Q + (live ? patch : 0) * vol * V;              // this thread's patch in HBM (writes)
     const double* Qp = Qg;                                       // ... and where the stencil reads it
     if constexpr (STAGE) {
@@ -218,8 +220,10 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
 // values of plane i go straight back to HBM in place: every plane is read once and its interior written once.
 template <class PDE, int MODE>
 __global__ void __launch_bounds__(256)
-fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h) {
+fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h,
+                       const long* __restrict__ slot) {
     extern __shared__ __attribute__((aligned(16))) double ring[];
+    if (slot && slot[blockIdx.x] < 0) return;                      // patch not in use (workgroup-uniform)
     const int S = P + 2 * H;
     const int plane = S * S * V;                                  // doubles per plane
     double* Qp = Q + (long)blockIdx.x * S * plane;
@@ -328,7 +332,7 @@ __global__ void pde_eval_kernel(int normal, long n, int stride, const double* __
 }
 
 template <int DIM, class PDE, int MODE>
-static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, hipStream_t s) {
+static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, const long* slot, hipStream_t s) {
     const long ncell = (DIM == 3) ? (long)P * P * P : (long)P * P;
     const double doh = (MODE == 1) ? dt / h : 0.0;
     const int S = P + 2 * H;
@@ -338,23 +342,23 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
         const dim3 grid((unsigned)((n_patches + ppb - 1) / ppb));
         const size_t lds = (size_t)ppb * pvol * V * sizeof(double);
         if (DIM == 2 && P == 4 && H == 1 && m == 5 && V == 10)      // the reference's configuration (Batched_stateless.py:9)
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
         else if (lds <= 64 * 1024)       // staged: up to two workgroups per CU keep HBM requests in flight
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
         else
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, false>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, false>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
     } else if (ncell <= 1024) {
         const size_t lds = (size_t)pvol * V * sizeof(double);
         if (lds <= 64 * 1024)
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
         else
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
     } else if (DIM == 3 && P * P <= 256 && (size_t)4 * S * S * V * sizeof(double) <= 64 * 1024) {
         // plane-streaming variant: 4-plane LDS ring, one workgroup per patch
         hipLaunchKernelGGL((fv_rusanov_slab_kernel<PDE, MODE>), dim3((unsigned)n_patches), dim3(256), (size_t)4 * S * S * V * sizeof(double), s,
-                           Q, P, H, m, V, dt, doh);
+                           Q, P, H, m, V, dt, doh, slot);
     } else if (ncell <= 4096) {
-        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1);
+        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
     }
     else {
         set_error("FV patch with %ld volumes exceeds the 4096 a workgroup keeps in registers", ncell);
@@ -366,9 +370,9 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
 }
 
 template <int DIM, class PDE>
-static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, hipStream_t s) {
-    if (mode == 0) return fv_dispatch<DIM, PDE, 0>(P, H, m, V, n_patches, Q, dt, h, s);
-    return fv_dispatch<DIM, PDE, 1>(P, H, m, V, n_patches, Q, dt, h, s);
+static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, const long* slot, hipStream_t s) {
+    if (mode == 0) return fv_dispatch<DIM, PDE, 0>(P, H, m, V, n_patches, Q, dt, h, slot, s);
+    return fv_dispatch<DIM, PDE, 1>(P, H, m, V, n_patches, Q, dt, h, slot, s);
 }
 
 #ifdef EXA_USER_PDE_HEADER
@@ -376,13 +380,13 @@ static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double*
 // user-PDE side library: the same fused kernel instantiated for exa::UserPDE
 extern "C" int exa_user_nv() { return exa::UserPDE::NV; }
 extern "C" int exa_user_fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                                  double h, void* stream) {
+                                  double h, const long* slot, void* stream) {
     using namespace exa;
     const int V = n_real + n_aux;
     if (n_real > MAXV || n_real < UserPDE::NV) { set_error("user PDE evolves %d variables; n_real = %d", UserPDE::NV, n_real); return -1; }
     if (n_patches <= 0) return 0;
-    if (dim == 2) return fv_mode<2, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, (hipStream_t)stream);
-    if (dim == 3 && UserPDE::MAXDIM >= 3) return fv_mode<3, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, (hipStream_t)stream);
+    if (dim == 2) return fv_mode<2, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, (hipStream_t)stream);
+    if (dim == 3 && UserPDE::MAXDIM >= 3) return fv_mode<3, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, (hipStream_t)stream);
     set_error("user PDE: no FV kernel for dim %d", dim);
     return -1;
 }
@@ -397,18 +401,18 @@ extern "C" int exa_user_pde_eval(int normal, long n, int stride, const double* Q
 namespace exa {
 #else
 int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
-              double h, hipStream_t s) {
+              double h, const long* slot, hipStream_t s) {
     const int V = n_real + n_aux;
     if (n_real > MAXV) { set_error("n_real = %d exceeds %d", n_real, MAXV); return -1; }
     if (n_patches <= 0) return 0;
-    if (pde >= 100) return user_fv_launch(pde, mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, s);
+    if (pde >= 100) return user_fv_launch(pde, mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, s);
     if (dim == 2) {
-        if (pde == 0) return fv_mode<2, EulerRef2D>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
-        if (pde == 1) return fv_mode<2, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
-        if (pde == 2) return fv_mode<2, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
+        if (pde == 0) return fv_mode<2, EulerRef2D>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
+        if (pde == 1) return fv_mode<2, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
+        if (pde == 2) return fv_mode<2, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
     } else if (dim == 3) {
-        if (pde == 1) return fv_mode<3, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
-        if (pde == 2) return fv_mode<3, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, s);
+        if (pde == 1) return fv_mode<3, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
+        if (pde == 2) return fv_mode<3, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
     }
     set_error("FV Rusanov: no kernel for dim %d, pde %d", dim, pde);
     return -1;

@@ -37,6 +37,7 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
                        LimGhosts gh) {
     __shared__ double A[LIM_MAX], B[LIM_MAX];
     const long cell = cells[blockIdx.x];
+    if (cell < 0) return;                                          // empty slot of a capacity-sized cell list
     const int S = Ns + 2;
     long NN = 1, SS = 1, NsD = 1;
     for (int a = 0; a < DIM; a++) { NN *= N; SS *= S; NsD *= Ns; }
@@ -171,6 +172,7 @@ limiter_reconstruct_kernel(int N, int Ns, int nv, const double* __restrict__ pat
                            double* __restrict__ u, const double* __restrict__ R) {
     __shared__ double A[LIM_MAX], B[LIM_MAX];
     const long cell = cells[blockIdx.x];
+    if (cell < 0) return;                                          // empty slot
     const int S = Ns + 2;
     long NN = 1, SS = 1, NsD = 1;
     for (int a = 0; a < DIM; a++) { NN *= N; SS *= S; NsD *= Ns; }

@@ -20,8 +20,11 @@ Recognised schemes
                          hint only; not expressible in the reference's surface.
 Anything else raises: there is no generic fallback and no CPU path.
 
-The user's opaque PDE terms (`Flux`, `maxEigenvalue`, `max`; resolved at link time
-to `Unit test/Functions.cpp` in the reference) map to built-in device term sets.
+The user's opaque PDE terms (resolved at link time to `Unit test/Functions.cpp` in the
+reference) must be named: `pde=` selects a built-in device term set or a SympyPDE,
+SymPy bodies on the builder's functions generate one; only functions named exactly
+`Flux`, `maxEigenvalue`, `max` (the reference's example) default to that example's
+Functions.cpp terms.  The choice is recorded in `.code`.
 """
 from __future__ import annotations
 
@@ -96,10 +99,26 @@ class HIPPrinter(CodePrinter):
         if scheme not in ("fv-rusanov-faithful", "fv-rusanov", "aderdg"):
             raise ValueError("unknown scheme %r" % scheme)
         self.scheme = scheme
+        # The PDE terms are opaque symbols in the reference (resolved at link time to the user's C++, Functions.h:2-4); a
+        # HIP kernel needs a device term set.  It is never guessed: explicit pde=, SymPy bodies, or -- for functions named
+        # exactly as in the reference's example (Flux / maxEigenvalue / max) -- that example's Functions.cpp.
+        self.pde_origin = "pde= argument"
+        if scheme == "fv-rusanov-faithful" and len(k.functions) == 3 and k.functions[2] != "max":
+            raise UnrecognisedKernel("the faithful FV Rusanov kernel implements the reference's `max` (Functions.cpp:64-66) as "
+                                     "third term; got %r" % k.functions[2])
         if pde is None:
             pde = self._pde_from_bodies(k)
+            if pde is not None:
+                self.pde_origin = "SymPy bodies of the builder's functions"
         if pde is None:
-            pde = "euler_ref2d" if (scheme != "aderdg" and k.dim == 2) else "euler"
+            if list(k.functions) == ["Flux", "maxEigenvalue", "max"] and scheme != "aderdg":
+                pde = "euler_ref2d" if k.dim == 2 else "euler"
+                self.pde_origin = "default: functions are named Flux / maxEigenvalue / max as in the reference's example, whose terms are Unit test/Functions.cpp"
+            else:
+                raise UnrecognisedKernel(
+                    "the PDE terms %s are opaque symbols: say which device term set they are with pde= (%s, or a "
+                    "pde_codegen.SympyPDE) or give the functions SymPy bodies -- a term set is never guessed"
+                    % (list(k.functions) or "(none declared)", ", ".join(sorted(PDE_IDS))))
         self.user_pde = None
         if hasattr(pde, "register") and hasattr(pde, "source"):      # a SympyPDE: compiled for the device on compile()
             self.user_pde = pde
@@ -150,7 +169,8 @@ class HIPPrinter(CodePrinter):
         L = ["// exahype_amd HIP dispatch plan for `%s` (MI355X / gfx950)" % self.functionName(),
              "// scheme     : %s" % self.scheme,
              "// pde terms  : %s  <- %s" % (_PDE_DOC.get(self.pde, "user term set from SymPy expressions (pde_codegen.SympyPDE, JIT-compiled)"),
-                                            ", ".join(k.functions))]
+                                            ", ".join(k.functions)),
+             "// chosen by  : %s" % self.pde_origin]
         if self.scheme == "aderdg":
             N = k.patch_size
             L += ["// kernels    : dg_stage_a_kernel<%d,%d> (predictor + volume + face traces), dg_stage_b_kernel<%d,%d> (Riemann + corrector)"

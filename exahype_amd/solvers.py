@@ -43,8 +43,10 @@ class FVRusanovKernel:
         self._plan = h
         self.count = self.lib.exa_fv_q_count(h)
 
-    def time_step(self, Q, dt, h=1.0):
-        """In place.  numpy array -> staged through HBM by the library; CUDA tensor -> no copies."""
+    def time_step(self, Q, dt, h=1.0, slot=None):
+        """In place.  numpy array -> staged through HBM by the library; CUDA tensor -> no copies.
+        slot (CUDA int64 tensor, one entry per patch): patches with a negative entry are skipped -- for patch arrays
+        whose number of entries in use is known on the device only."""
         if isinstance(Q, np.ndarray):
             if Q.dtype != np.float64 or not Q.flags.c_contiguous or Q.size != self.count:
                 raise ValueError("Q must be a C-contiguous float64 array of %d entries" % self.count)
@@ -53,6 +55,12 @@ class FVRusanovKernel:
         torch = _torch()
         if not (Q.is_cuda and Q.dtype == torch.float64 and Q.is_contiguous() and Q.numel() == self.count):
             raise ValueError("Q must be a contiguous float64 CUDA tensor of %d entries" % self.count)
+        if slot is not None:
+            if not (slot.is_cuda and slot.dtype == torch.int64 and slot.is_contiguous() and slot.numel() >= self.shape[0]):
+                raise ValueError("slot must be a contiguous int64 CUDA tensor with one entry per patch")
+            check(self.lib.exa_fv_time_step_device_masked(self._plan, C.c_void_p(Q.data_ptr()), C.c_void_p(slot.data_ptr()),
+                                                          dt, h, _stream_ptr()))
+            return Q
         check(self.lib.exa_fv_time_step_device(self._plan, C.c_void_p(Q.data_ptr()), dt, h, _stream_ptr()))
         return Q
 
@@ -249,6 +257,11 @@ class AderDgSolver:
         self.halo = None
         self._fused = bool(fused_single_stage) and bool(self.lib.exa_dg_has_fused_step(h))
         self._u2 = None
+        # measurement hooks (bench.py): stage_a_events collects one (start, end) event pair per stage-A launch on the
+        # launching stream; exchange_events one (shell done, comm start, comm end, interior start, interior end) tuple
+        # per sharded step.  None = off: the product path records nothing.
+        self.stage_a_events = None
+        self.exchange_events = None
         if part is not None and part.world > 1:
             self.halo = HaloExchange(part, self.nc, self.ts, self.dev, stage_through_host=backend_is_gloo)
             self.comm_stream = torch.cuda.Stream(device=self.dev)
@@ -279,9 +292,17 @@ class AderDgSolver:
 
     # -- kernels -------------------------------------------------------------------------------
     def predictor_volume(self, dt, lo=None, hi=None):
+        ev = None
+        if self.stage_a_events is not None:
+            torch = _torch()
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         check(self.lib.exa_dg_predictor_volume_box(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
                                                    larr(lo) if lo is not None else None, larr(hi) if hi is not None else None,
                                                    dt, darr(self.dx), _stream_ptr()))
+        if ev is not None:
+            ev[1].record()
+            self.stage_a_events.append(ev)
 
     def riemann_corrector(self, dt, lo=None, hi=None):
         ghosts = self.halo.ghost_ptrs() if self.halo is not None else None
@@ -294,6 +315,16 @@ class AderDgSolver:
         out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         check(self.lib.exa_dg_max_eigenvalue(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(out.data_ptr()), _stream_ptr()))
         return out
+
+    def _pack_faces(self):
+        """Outward traces of the block's boundary layers -> the contiguous send buffers (exa_dg_pack_face: one strided
+        device copy per face, on the current stream)."""
+        for d in range(self.dim):
+            if not self.part.partitioned(d):
+                continue
+            for side in range(2):
+                check(self.lib.exa_dg_pack_face(self._plan, C.c_void_p(self.trace.data_ptr()), d, side,
+                                                C.c_void_p(self.halo.send[d * 2 + side].data_ptr()), _stream_ptr()))
 
     def step(self, dt):
         """One ADER-DG time step of the block (periodic, or one shard of a periodic grid)."""
@@ -313,21 +344,34 @@ class AderDgSolver:
             self.riemann_corrector(dt)
             return
         cur = torch.cuda.current_stream(self.dev)
+        timed = self.exchange_events is not None
+        mk = (lambda: torch.cuda.Event(enable_timing=True)) if timed else (lambda: None)
         for lo, hi in self.shell:                      # boundary shell first ...
             self.predictor_volume(dt, lo, hi)
-        ready = torch.cuda.Event()
+        ready = torch.cuda.Event(enable_timing=timed)
         ready.record(cur)
+        c0, c1, i0, i1 = mk(), mk(), mk(), mk()
         with torch.cuda.stream(self.comm_stream):      # ... its traces travel on the comm stream ...
             self.comm_stream.wait_event(ready)
-            self.halo.pack(self.trace)
+            if timed:
+                c0.record()
+            self._pack_faces()
             self.halo.start()
         lo, hi = self.interior                         # ... while the interior cells run stage A
+        if timed:
+            i0.record()
         if all(h > l for l, h in zip(lo, hi)):
             self.predictor_volume(dt, lo, hi)
+        if timed:
+            i1.record()
         with torch.cuda.stream(self.comm_stream):
             self.halo.finish()
+            if timed:
+                c1.record()
         cur.wait_stream(self.comm_stream)
         self.riemann_corrector(dt)
+        if timed:
+            self.exchange_events.append((ready, c0, c1, i0, i1))
 
     def __del__(self):
         try:
@@ -364,12 +408,40 @@ def fill_halos_periodic(Q, grid, dim, patch_size, halo_size):
     return Q
 
 
+def fill_halos_dirichlet(Q, grid, dim, patch_size, halo_size, boundary):
+    """Halo fill of a NON-periodic Cartesian grid of patches: interior patch faces take the neighbour's interior layers
+    (as fill_halos_periodic), the halo layers on the domain boundary are set to the prescribed state.
+
+    boundary: array-like broadcastable to [..., V] (one fixed state for the whole boundary), or a dict
+    {(axis, side): state} with side 0 = low, 1 = high face.  Edge / corner halo entries on the boundary get the state of
+    the LAST axis that touches them (axes are filled in order); the 2*dim+1-point Rusanov stencil never reads them."""
+    P, H, S = patch_size, halo_size, patch_size + 2 * halo_size
+    fill_halos_periodic(Q, grid, dim, patch_size, halo_size)      # interior faces (the wrap entries are overwritten below)
+    is_np = isinstance(Q, np.ndarray)
+
+    def state(a, side):
+        b = boundary[(a, side)] if isinstance(boundary, dict) else boundary
+        if is_np:
+            return np.asarray(b, dtype=Q.dtype)
+        torch = _torch()
+        return torch.as_tensor(np.asarray(b, dtype=np.float64), dtype=Q.dtype, device=Q.device)
+    for a in range(dim):
+        lo = [slice(None)] * Q.ndim
+        hi = [slice(None)] * Q.ndim
+        lo[a], lo[dim + a] = 0, slice(0, H)                      # first patch along a: its low halo layers
+        hi[a], hi[dim + a] = grid[a] - 1, slice(P + H, S)        # last patch along a: its high halo layers
+        Q[tuple(lo)] = state(a, 0)
+        Q[tuple(hi)] = state(a, 1)
+    return Q
+
+
 class FVPatchGrid:
-    """A periodic Cartesian grid of FV patches resident in HBM, advanced by the fused Rusanov kernel:
-    halo fill -> `time_step` for every patch -> ... ; dt from the CFL condition when asked."""
+    """A Cartesian grid of FV patches resident in HBM, advanced by the fused Rusanov kernel:
+    halo fill (periodic, or Dirichlet with `boundary=`) -> `time_step` for every patch -> ... ; dt from the CFL
+    condition when asked."""
 
     def __init__(self, dim, grid, patch_size, halo_size=1, n_real=5, n_aux=0, pde=PDE_EULER, mode=FV_RUSANOV,
-                 length=1.0, device=0):
+                 length=1.0, device=0, boundary=None):
         torch = _torch()
         self.dim, self.grid, self.P, self.H = dim, tuple(int(g) for g in grid), patch_size, halo_size
         self.n_real, self.n_aux, self.pde = n_real, n_aux, pde
@@ -380,6 +452,13 @@ class FVPatchGrid:
         self.Q = torch.zeros(self.grid + (S,) * dim + (n_real + n_aux,), dtype=torch.float64,
                              device=torch.device("cuda", device))
         self.time = 0.0
+        self.boundary = boundary                                      # None: periodic
+
+    def fill_halos(self):
+        if self.boundary is None:
+            fill_halos_periodic(self.Q, self.grid, self.dim, self.P, self.H)
+        else:
+            fill_halos_dirichlet(self.Q, self.grid, self.dim, self.P, self.H, self.boundary)
 
     def set_interior(self, values):
         """values: [g.., P.., V] (numpy or tensor)."""
@@ -405,14 +484,14 @@ class FVPatchGrid:
         return best
 
     def step(self, dt):
-        fill_halos_periodic(self.Q, self.grid, self.dim, self.P, self.H)
+        self.fill_halos()
         self.kernel.time_step(self.Q, dt, self.h)
         self.time += dt
 
     def run(self, t_end, cfl=0.4, max_steps=1000000):
         steps = 0
         while self.time < t_end * (1 - 1e-14) and steps < max_steps:
-            fill_halos_periodic(self.Q, self.grid, self.dim, self.P, self.H)
+            self.fill_halos()
             dt = min(cfl * self.h / (self.dim * self.max_eigenvalue()), t_end - self.time)
             self.kernel.time_step(self.Q, dt, self.h)
             self.time += dt
@@ -452,11 +531,24 @@ class SubcellLimiter:
     boundary layers, then -- only where the cell across the face is troubled -- the adjacent subcell layer of the
     boundary cells; the patches of troubled cells at a block face take their halo from those."""
 
-    def __init__(self, solver):
+    def __init__(self, solver, capacity=None):
+        """capacity: upper bound of the number of troubled cells per step (default: every cell of the block); the FV
+        patch array [capacity][(N_s+2)^dim][n_vars] is allocated once (196 KB per patch at p = 7)."""
+        torch = _torch()
         self.s = solver
         self.Ns = 2 * solver.N - 1
         self.patch_doubles = solver.lib.exa_lim_patch_count(solver._plan)
-        self._fv = {}
+        ncell = int(np.prod(solver.nc))
+        self.capacity = ncell if capacity is None else max(1, min(int(capacity), ncell))
+        self._patches = torch.empty((self.capacity, self.patch_doubles), dtype=torch.float64, device=solver.dev)
+        self._cells = torch.full((self.capacity + 1,), -1, dtype=torch.int64, device=solver.dev)     # + dump slot
+        self._arange = torch.arange(ncell, dtype=torch.int64, device=solver.dev)
+        self._fv = FVRusanovKernel(solver.dim, self.Ns, 1, solver.nv, 0, self.capacity, pde=solver.pde, mode=FV_RUSANOV,
+                                   device=solver.dev.index or 0)
+        self.overflow = torch.zeros((), dtype=torch.bool, device=solver.dev)
+        self._ovf_host = torch.zeros(1, dtype=torch.uint8).pin_memory()
+        self._ovf_event = torch.cuda.Event()
+        self._ovf_event.record(torch.cuda.current_stream(solver.dev))
         self.hx_mask = self.hx_layer = None
         if solver.halo is not None:
             stage = solver.halo.stage
@@ -537,24 +629,53 @@ class SubcellLimiter:
         return hl.ghost_ptrs()
 
     def step(self, dt, mask):
+        """One limited step.  mask: troubled flags [nc0, nc1, (nc2)] (CUDA bool tensor stays on the device; numpy is
+        uploaded).  Nothing in here waits for the GPU: the troubled cells are compacted on the device into a
+        capacity-sized list (empty slots = -1) that the projection, the FV patch update and the reconstruction
+        skip, and one FV plan of `capacity` patches serves every step.  Returns the number of troubled cells as a
+        0-dim CUDA tensor (int(...) of it synchronises; the kernels do not need it).  More troubled cells than
+        `capacity` cannot be served: `self.overflow` (0-dim CUDA bool) says so -- see check()."""
         torch = _torch()
         s = self.s
-        m = torch.as_tensor(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask)).to(s.dev)
-        cells = torch.nonzero(m.reshape(-1), as_tuple=False).reshape(-1).to(torch.int64).contiguous()
-        n = int(cells.numel())
+        if isinstance(mask, torch.Tensor):
+            m = mask.to(device=s.dev, dtype=torch.bool)
+        else:
+            m = torch.as_tensor(np.ascontiguousarray(mask), dtype=torch.bool).to(s.dev, non_blocking=True)
+        m = m.reshape(-1)
+        ncell, cap = m.numel(), self.capacity
+        # device-side compaction without a host-visible size: cell c goes to slot (number of troubled cells before it)
+        rank = torch.cumsum(m, 0, dtype=torch.int64)
+        count = rank[-1]
+        pos = torch.where(m & (rank <= cap), rank - 1, torch.full_like(rank, cap))       # cap = dump slot
+        self._cells.fill_(-1)
+        self._cells.scatter_(0, pos, self._arange)
+        self._cells[cap] = -1
+        self.overflow = count > cap
+        self._post_overflow()
+        cells = self._cells
         ghosts = None
         if self.hx_layer is not None:                          # every rank takes part, troubled cells or not
             nc3 = s.nc + [1] * (3 - s.dim)
             ghosts = self._exchange_subcell_layers(m.to(torch.float64).reshape(nc3))
-        patches = torch.empty((max(n, 1), self.patch_doubles), dtype=torch.float64, device=s.dev)
-        check(s.lib.exa_dg_project_patches_ghost(s._plan, C.c_void_p(s.u.data_ptr()), C.c_void_p(cells.data_ptr()), n,
+        patches = self._patches
+        check(s.lib.exa_dg_project_patches_ghost(s._plan, C.c_void_p(s.u.data_ptr()), C.c_void_p(cells.data_ptr()), cap,
                                                  C.c_void_p(patches.data_ptr()), ghosts, _stream_ptr()))
         s.step(dt)                                             # candidate DG solution everywhere
-        if n == 0:
-            return 0
-        if n not in self._fv:                                  # one plan per patch count; keep only the current one
-            self._fv = {n: FVRusanovKernel(s.dim, self.Ns, 1, s.nv, 0, n, pde=s.pde, mode=FV_RUSANOV, device=s.dev.index or 0)}
-        self._fv[n].time_step(patches[:n].reshape(-1), dt, s.dx[0] / self.Ns)
-        check(s.lib.exa_dg_reconstruct_patches(s._plan, C.c_void_p(patches.data_ptr()), C.c_void_p(cells.data_ptr()), n,
+        self._fv.time_step(patches.reshape(-1), dt, s.dx[0] / self.Ns, slot=cells)
+        check(s.lib.exa_dg_reconstruct_patches(s._plan, C.c_void_p(patches.data_ptr()), C.c_void_p(cells.data_ptr()), cap,
                                                C.c_void_p(s.u.data_ptr()), _stream_ptr()))
-        return n
+        return count
+
+    def _post_overflow(self):
+        """Copy the overflow flag to pinned host memory behind an event; check() reads it once the event has passed."""
+        torch = _torch()
+        self._ovf_host.copy_(self.overflow.to(torch.uint8), non_blocking=True)
+        self._ovf_event.record(torch.cuda.current_stream(self.s.dev))
+
+    def check(self, wait=False):
+        """Raise if a finished step had more troubled cells than `capacity` (those beyond it kept the DG result).
+        Without `wait` only steps the GPU has already completed are looked at (no synchronisation)."""
+        if wait:
+            self._ovf_event.synchronize()
+        if self._ovf_event.query() and bool(self._ovf_host[0]):
+            raise RuntimeError("SubcellLimiter: more troubled cells than capacity = %d" % self.capacity)

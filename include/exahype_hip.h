@@ -88,6 +88,11 @@ long exa_fv_q_count(const exa_fv_plan* plan);
 int exa_fv_time_step_host(exa_fv_plan* plan, double* Q_host, double dt, double h);
 /* same on a device-resident array (the hot path: no PCIe in the call) */
 int exa_fv_time_step_device(exa_fv_plan* plan, double* Q_dev, double dt, double h, void* stream);
+/* same over a patch array of which only some entries are in use, their number known on the device only (the
+ * limiter's troubled cells): the launch covers the plan's n_patches (the array's capacity) and skips every
+ * patch p with slot_dev[p] < 0.  slot_dev == NULL: all patches (== exa_fv_time_step_device). */
+int exa_fv_time_step_device_masked(exa_fv_plan* plan, double* Q_dev, const long* slot_dev, double dt, double h,
+                                   void* stream);
 
 /* ---- ADER-DG cell kernels ---------------------------------------------------- */
 /* N = order + 1 nodes per axis; n_vars must equal the PDE's variable count (5 for
@@ -138,7 +143,9 @@ int exa_dg_pack_face(exa_dg_plan* plan, const double* trace_dev, int d, int side
  * reconstruction R[N][N_s].  exa_dg_project_patches: for the n cells listed in cells_dev build FV patches
  * patch_dev[n][(N_s+2)^dim][n_vars] (patch_size N_s, halo 1: interior = projected cell, face halos = adjacent
  * subcell layer of the projected face neighbours, periodic in the block) ready for exa_fv_time_step_device;
- * exa_dg_reconstruct_patches maps the patch interiors back onto the DG nodes of those cells. */
+ * exa_dg_reconstruct_patches maps the patch interiors back onto the DG nodes of those cells.
+ * cells_dev[i] < 0 marks an empty slot of a capacity-sized list (patch i is then neither written nor read): the list
+ * can be compacted on the device without the host ever learning how many cells are troubled. */
 int exa_lim_operators(const exa_dg_plan* plan, double* P, double* R);
 long exa_lim_patch_count(const exa_dg_plan* plan);
 int exa_dg_project_patches(exa_dg_plan* plan, const double* u_dev, const long* cells_dev, long n, double* patch_dev,

@@ -51,6 +51,8 @@ def lib():
         L.orc_aderdg_stage_a.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_long, _dp, C.c_double, _dp, _dp, _dp]
         L.orc_aderdg_stage_b.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _lp, _dp, _dp, C.c_double, _dp, _dp]
         L.orc_aderdg_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _lp, _dp, C.c_double, _dp]
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_aderdg_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _lp, _dp, C.c_double, _dp, C.c_int]
         _lib = L
     return _lib
 
@@ -116,6 +118,13 @@ def aderdg_step(u, dt, dx, ops, dim, N, m, pde, n_it, nc):
     u = np.ascontiguousarray(u, dtype=np.float64).copy()
     lib().orc_aderdg_step(dim, N, m, pde, n_it, pack_ops(ops), np.asarray(nc, dtype=np.int64), u.ravel(), dt,
                           np.asarray(dx, dtype=np.float64))
+    return u
+
+
+def aderdg_run(u, dt, dx, ops, dim, N, m, pde, n_it, nc, n_steps):
+    """n_steps steps IN PLACE on the C-contiguous float64 array u (work arrays allocated once; timing aid)."""
+    lib().orc_aderdg_run(dim, N, m, pde, n_it, pack_ops(ops), np.asarray(nc, dtype=np.int64), u.ravel(), dt,
+                         np.asarray(dx, dtype=np.float64), n_steps)
     return u
 
 

@@ -25,6 +25,7 @@
  * u[cell][node][var], cell = (cx*ny+cy)*nz+cz, node = (i*N+j)*N+k; axis 0 is
  * the reference's `i` (normal = 0).
  */
+#include <omp.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -449,5 +450,25 @@ void orc_aderdg_step(int dim, int N, int m, int pde, int n_it, const double* ops
     double* tr = (double*)malloc((size_t)dim * 2 * ncells * 2 * m * Nf * sizeof(double));
     orc_aderdg_stage_a(dim, N, m, pde, n_it, ops, ncells, u, dt, dx, us, tr);
     orc_aderdg_stage_b(dim, N, m, pde, ops, nc, us, tr, dt, dx, u);
+    free(us); free(tr);
+}
+
+/* OpenMP team size of the restatement's parallel loops (bench.py's CPU-baseline leg: one thread per usable core). */
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_get_max_threads(void) { return omp_get_max_threads(); }
+
+/* n_steps full steps on a periodic grid, in place on u; ustar + traces are allocated ONCE (bench.py's CPU-baseline
+ * leg: no allocation inside the timed steps).  Same arithmetic as n_steps calls of orc_aderdg_step. */
+void orc_aderdg_run(int dim, int N, int m, int pde, int n_it, const double* ops, const long* nc, double* u, double dt,
+                    const double* dx, int n_steps) {
+    const long nn = ipow(N, dim), Nf = ipow(N, dim - 1);
+    long ncells = 1;
+    for (int d = 0; d < dim; d++) ncells *= nc[d];
+    double* us = (double*)malloc((size_t)ncells * nn * m * sizeof(double));
+    double* tr = (double*)malloc((size_t)dim * 2 * ncells * 2 * m * Nf * sizeof(double));
+    for (int s = 0; s < n_steps; s++) {
+        orc_aderdg_stage_a(dim, N, m, pde, n_it, ops, ncells, u, dt, dx, us, tr);
+        orc_aderdg_stage_b(dim, N, m, pde, ops, nc, us, tr, dt, dx, u);
+    }
     free(us); free(tr);
 }

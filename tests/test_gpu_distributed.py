@@ -1,8 +1,11 @@
 """The sharded ADER-DG step (boundary shell first, face-trace exchange on a second stream, interior
-overlapped) on real kernels: 2 ranks share cuda:0 and exchange over gloo (host-staged); the result
+overlapped) on real kernels: 2 or 4 ranks share cuda:0 and exchange over gloo (host-staged); the result
 must equal the oracle's step of the whole periodic grid.  (RCCL itself needs one GPU per rank; the
-driver's 8-GPU run exercises that backend with the same code path.)"""
+driver's 8-GPU run exercises that backend with the same code path.)  cfg 3 runs at its own order
+(N = 6: the persistent LDS-resident stage A on shell / interior boxes, the dense stage B with ghost
+buffers in one and in two directions), cfg 4 at its own (N = 8: level-streamed stage A + 17^3 FV patches)."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -10,6 +13,33 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _run_ranks(tmp_path, text, world, timeout=600):
+    script = tmp_path / "worker.py"
+    script.write_text(text)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:                                   # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
 
 WORKER = r'''
 import os, sys
@@ -45,20 +75,13 @@ print("rank", rank, "rel err", err)
 '''
 
 
-@pytest.mark.parametrize("N,nc,pdims", [(3, (2, 3, 2), [2, 1, 1]), (4, (3, 2, 2), [1, 2, 1]), (3, (1, 2, 3), [2, 1, 1])])
+@pytest.mark.parametrize("N,nc,pdims", [(3, (2, 3, 2), [2, 1, 1]), (4, (3, 2, 2), [1, 2, 1]), (3, (1, 2, 3), [2, 1, 1]),
+                                         (6, (2, 2, 2), [2, 1, 1]),      # cfg 3's order, one partitioned direction
+                                         (6, (2, 2, 2), [2, 2, 1]),      # cfg 3's order, 4 ranks: ghosts in two directions
+                                         (6, (3, 2, 2), [1, 2, 2])])     # 4 ranks, the other two directions; interior box non-empty in x
 def test_sharded_step_equals_global_oracle(tmp_path, N, nc, pdims):
-    world = 2
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % dict(root=ROOT, N=N, nc=nc, pdims=pdims))
-    port = 29500 + (os.getpid() + N * 13 + nc[0]) % 2000
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    world = pdims[0] * pdims[1] * pdims[2]
+    _run_ranks(tmp_path, WORKER % dict(root=ROOT, N=N, nc=nc, pdims=pdims), world)
 
 
 LIM_WORKER = r'''
@@ -103,18 +126,8 @@ print("rank", rank, "rel err", err)
 '''
 
 
-@pytest.mark.parametrize("dim,N,nc,pdims", [(2, 3, (2, 3), [2, 1]), (3, 3, (2, 2, 1), [1, 2, 1]), (2, 4, (3, 1), [1, 2])])
+@pytest.mark.parametrize("dim,N,nc,pdims", [(2, 3, (2, 3), [2, 1]), (3, 3, (2, 2, 1), [1, 2, 1]), (2, 4, (3, 1), [1, 2]),
+                                             (3, 8, (2, 1, 2), [2, 1, 1])])      # cfg 4's order: p = 7, 17^3 patches
 def test_sharded_limited_step_equals_global_oracle(tmp_path, dim, N, nc, pdims):
     """cfg 4 across ranks: troubled cells at a block face take their FV halo from the neighbour block's subcell layer."""
-    world = 2
-    script = tmp_path / "worker.py"
-    script.write_text(LIM_WORKER % dict(root=ROOT, dim=dim, N=N, nc=nc, pdims=pdims))
-    port = 31500 + (os.getpid() + N * 13 + nc[0] + dim) % 2000
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    _run_ranks(tmp_path, LIM_WORKER % dict(root=ROOT, dim=dim, N=N, nc=nc, pdims=pdims), 2)

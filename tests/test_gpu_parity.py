@@ -183,8 +183,50 @@ def test_dg_box_launches_cover_block(exa, orc):
         b.predictor_volume(dt, lo, hi)
     for lo, hi in shell + [interior]:
         b.riemann_corrector(dt, lo, hi)
-    # (not bitwise: the three directions of a Picard iteration add into S with LDS atomics, in any order)
+    # (a box launch enumerates the cells in another order than the block launch; the arithmetic per cell is the same)
     assert rel_err(a.download(), b.download()) < 1e-13
+
+
+@pytest.mark.parametrize("N,nc", [(6, (12, 10, 9)), (8, (7, 7, 6)), (4, (13, 11, 9)), (5, (9, 8, 8))])
+def test_dg_persistent_grid_multipass_vs_oracle(exa, orc, N, nc):
+    """More cell blocks than resident workgroups, and not a multiple of them: the persistent grid of stage A walks
+    over several blocks per workgroup (`blk += gridDim.x`: cell-id ping-pong, prefetch of the next block's u, LDS
+    image reused) -- the regime the 128^3 benchmark runs in.  1 080 cells at N = 6 and 294 at N = 8 against 256
+    resident workgroups; 322 blocks of 4 cells at N = 4, 288 blocks of 2 cells at N = 5 (CPB > 1)."""
+    ops = _ops(N)
+    u = euler_dg_state(tuple(nc) + (N,) * 3, seed=500 + N)
+    dx = [1.0 / c for c in nc]
+    dt = 0.02 * min(dx) / (2 * N - 1)
+    s = exa.AderDgSolver(3, N, nc, dx=dx)
+    s.upload(u)
+    s.predictor_volume(dt)
+    us_o, tr_o = orc.aderdg_stage_a(u.reshape(-1), dt, dx, ops, 3, N, 5, orc.PDE_EULER, N)
+    assert rel_err(s.download().reshape(-1), us_o) < TOL                       # a stale / missing u* write-back shows here
+    assert rel_err(s.trace.cpu().numpy().reshape(tr_o.shape), tr_o) < TOL
+    s.upload(u)
+    uo = u.reshape(-1).copy()
+    for _ in range(2):
+        s.step(dt)
+        uo = orc.aderdg_step(uo, dt, dx, ops, 3, N, 5, orc.PDE_EULER, N, nc)
+    assert rel_err(s.download().reshape(-1), uo) < TOL
+
+
+def test_dg_box_launches_multipass_n6(exa, orc):
+    """cfg 3's order on shell / interior boxes of a block with more cells than resident workgroups: stage A (N = 6,
+    persistent grid) over the boxes of the 2x2x2 partition + stage B box by box == the oracle's step of the block."""
+    N, nc = 6, (9, 8, 7)
+    ops = _ops(N)
+    u = euler_dg_state(tuple(nc) + (N,) * 3, seed=606)
+    dx = [1.0 / c for c in nc]
+    dt = 0.02 * min(dx) / (2 * N - 1)
+    b = exa.AderDgSolver(3, N, nc, dx=dx); b.upload(u)
+    shell, interior = exa.CartesianPartition(8, 0, 3).shell_and_interior(nc)
+    for lo, hi in shell + [interior]:
+        b.predictor_volume(dt, lo, hi)
+    for lo, hi in shell + [interior]:
+        b.riemann_corrector(dt, lo, hi)
+    want = orc.aderdg_step(u.reshape(-1), dt, dx, ops, 3, N, 5, orc.PDE_EULER, N, nc)
+    assert rel_err(b.download().reshape(-1), want) < TOL
 
 
 def test_dg_advection_polynomial_exactness(exa):
@@ -225,16 +267,27 @@ def test_dg_rejects_unsupported(exa):
 
 
 # ---- through the operator surface --------------------------------------------------------------------
-def test_hip_printer_runs_reference_example_kernel(exa, golden_dir):
-    """KernelBuilder script -> HIPPrinter -> fused HIP kernel == the reference's generated time_step."""
+def test_hip_printer_runs_builder_script(exa, orc):
+    """A Rusanov patch-update script written against the operator surface (own names, 3-D, 5+2 variables, 3 patches) ->
+    HIPPrinter -> fused HIP kernel; expected output: the oracle's faithful restatement (pinned bit for bit against the
+    compiled reference, tests/test_oracle_pinning.py), compared BIT-EXACT."""
     from exahype_amd import KernelBuilder
     from exahype_amd.printers import HIPPrinter
-    from tests.example_kernels import batched_stateless
-    g = json.load(open(os.path.join(golden_dir, "fv_ref2d_sin.json")))
-    p = HIPPrinter(batched_stateless(KernelBuilder))
-    Q = np.sin(3.141 * np.arange(360) / 360)
-    p.run(Q, 1.0)
-    assert np.array_equal(Q[np.array(g["valid_modified_idx"])], np.array(g["valid_modified_val"]))
+    from tests.ref_examples import rusanov_patch_update
+    dim, P, H, m, aux, n = 3, 6, 1, 5, 2, 3
+    p = HIPPrinter(rusanov_patch_update(KernelBuilder, dim, P, H, m, aux, n))
+    assert p.scheme == "fv-rusanov-faithful" and p.pde == 1
+    Q = euler_patches(n, dim, P + 2 * H, m + aux, seed=99)
+    want = orc.fv_faithful(Q, 0.07, dim, P, H, m, aux, n, orc.PDE_EULER)
+    got = np.ascontiguousarray(Q.copy())
+    p.run(got, 0.07)
+    assert np.array_equal(got, want)
+    # and the reference's own configuration (2-D, P=4, H=1, 5+5), same script: its golden vector
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fv_ref2d_sin.json")))
+    p2 = HIPPrinter(rusanov_patch_update(KernelBuilder, 2, 4, 1, 5, 5, 1))
+    Q2 = np.sin(3.141 * np.arange(360) / 360)
+    p2.run(Q2, 1.0)
+    assert np.array_equal(Q2[np.array(g["valid_modified_idx"])], np.array(g["valid_modified_val"]))
 
 
 def test_hip_printer_aderdg_hint(exa, orc):
@@ -246,7 +299,7 @@ def test_hip_printer_aderdg_hint(exa, orc):
     u = euler_dg_state(nc + (N,) * 3, seed=8).reshape(8, N, N, N, 5)
     dx = [0.5] * 3
     want = orc.aderdg_step(u.reshape(-1), 1e-3, dx, _ops(N), 3, N, 5, orc.PDE_EULER, N, nc)
-    HIPPrinter(k, scheme="aderdg").run(u, 1e-3, dx=dx)
+    HIPPrinter(k, scheme="aderdg", pde="euler").run(u, 1e-3, dx=dx)
     assert rel_err(u.reshape(-1), want) < TOL
 
 

@@ -42,6 +42,61 @@ def test_fill_halos_periodic_matches_global_array(dim, grid, P, H):
     assert np.array_equal(Qt.numpy(), want)
 
 
+@pytest.mark.parametrize("dim,grid,P,H", [(2, (3, 2), 4, 1), (2, (1, 2), 3, 2), (3, (2, 2, 3), 3, 1)])
+def test_fill_halos_dirichlet_matches_global_array(dim, grid, P, H):
+    """SURVEY.md 8(f)-3, non-periodic: patches cut from a global array that is padded with fixed boundary values."""
+    from exahype_amd.solvers import fill_halos_dirichlet
+    rng = np.random.default_rng(1)
+    V = 3
+    G = rng.random(tuple(g * P for g in grid) + (V,))
+    states = {(a, s): rng.random(V) + 10 * (2 * a + s + 1) for a in range(dim) for s in range(2)}
+    # global array with H boundary layers per side; axes padded in order, so edges / corners hold the last axis' state
+    Gp = G
+    for a in range(dim):
+        lo_shape = list(Gp.shape); lo_shape[a] = H
+        lo = np.broadcast_to(states[(a, 0)], lo_shape); hi = np.broadcast_to(states[(a, 1)], lo_shape)
+        Gp = np.concatenate([lo, Gp, hi], axis=a)
+    S = P + 2 * H
+    want = np.zeros(tuple(grid) + (S,) * dim + (V,))
+    for idx in np.ndindex(*grid):
+        want[idx] = Gp[tuple(slice(idx[a] * P, idx[a] * P + S) for a in range(dim))]
+    mask = np.zeros(want.shape[dim:2 * dim], dtype=bool)
+    mask[(slice(H, H + P),) * dim] = True
+    # what the (2 dim + 1)-point stencil reads: interiors and face halos (one axis out of the interior range at most)
+    coords = np.indices((S,) * dim)
+    outside = sum(((coords[a] < H) | (coords[a] >= H + P)).astype(int) for a in range(dim))
+    read = outside <= 1
+    for lib in ("numpy", "torch"):
+        Q = want.copy()
+        Q[(slice(None),) * dim + (~mask,)] = -7.0
+        if lib == "torch":
+            import torch
+            Qt = torch.as_tensor(Q)
+            fill_halos_dirichlet(Qt, grid, dim, P, H, states)
+            Q = Qt.numpy()
+        else:
+            fill_halos_dirichlet(Q, grid, dim, P, H, states)
+        assert np.array_equal(Q[(slice(None),) * dim + (read,)], want[(slice(None),) * dim + (read,)])
+    # one fixed state for the whole boundary
+    Q = want.copy()
+    fill_halos_dirichlet(Q, grid, dim, P, H, np.full(V, 2.5))
+    assert np.all(Q[(0,) * dim][(slice(0, H),) + (slice(H, H + P),) * (dim - 1)] == 2.5)
+    assert np.array_equal(Q[(slice(None),) * dim + (mask,)], want[(slice(None),) * dim + (mask,)])
+
+
+@pytest.mark.gpu
+def test_fv_patch_grid_dirichlet_keeps_a_constant_state():
+    """A uniform state with the same state prescribed on the boundary is a fixed point of the Dirichlet-driven loop."""
+    from exahype_amd import solvers as exa
+    grid, P, H = (2, 3), 4, 1
+    state = np.array([1.2, 0.3, -0.2, 0.1, 2.9])
+    fv = exa.FVPatchGrid(2, grid, P, H, 5, 0, exa.PDE_EULER, exa.FV_RUSANOV, boundary=state)
+    fv.set_interior(np.broadcast_to(state, grid + (P, P, 5)).copy())
+    for _ in range(3):
+        fv.step(1e-3)
+    assert np.max(np.abs(fv.interior() - state)) < 1e-14
+
+
 @pytest.mark.gpu
 def test_fv_patch_grid_equals_one_big_periodic_patch():
     """A 3x2 grid of 4x4 patches advanced with halo fills == the oracle's update of the one 12x8 periodic patch."""

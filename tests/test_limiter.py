@@ -32,7 +32,9 @@ def _fv(dim, nv, pde):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,N,nc", [(2, 4, (4, 3)), (3, 3, (2, 2, 3)), (2, 2, (3, 3))])
+@pytest.mark.parametrize("dim,N,nc", [(2, 4, (4, 3)), (3, 3, (2, 2, 3)), (2, 2, (3, 3)),
+                                       (3, 8, (2, 1, 2)),        # cfg 4's order: level-streamed stage A + 17^3 slab FV update + reconstruction
+                                       (3, 7, (1, 2, 2))])
 def test_limited_step_vs_oracle(dim, N, nc):
     from exahype_amd import solvers as exa
     ops = operators(N)
@@ -59,6 +61,40 @@ def test_limited_step_vs_oracle(dim, N, nc):
     s.upload(u); lim.step(dt, mask)
     a, b = s.download(), s2.download()
     assert np.array_equal(a[~mask], b[~mask]) and not np.allclose(a[mask], b[mask], rtol=1e-9, atol=0)
+
+
+@pytest.mark.gpu
+def test_limiter_capacity_and_device_resident_mask():
+    """The troubled count never reaches the host inside step(): the cell list is compacted on the device into `capacity`
+    slots.  A CUDA mask gives the same result as a numpy mask; more troubled cells than capacity is reported by check()."""
+    import torch
+    from exahype_amd import solvers as exa
+    dim, N, nc = 2, 3, (4, 4)
+    u = euler_dg_state(tuple(nc) + (N,) * dim, seed=3)
+    dx = [0.25] * dim
+    dt = 0.02 * dx[0] / (2 * N - 1)
+    mask = np.zeros(nc, dtype=bool)
+    mask[0, 0] = mask[2, 1] = mask[3, 3] = True
+    res = []
+    for cap, m in ((None, mask), (3, torch.as_tensor(mask).cuda()), (5, mask)):
+        s = exa.AderDgSolver(dim, N, nc, dx=dx)
+        lim = exa.SubcellLimiter(s, capacity=cap)
+        s.upload(u)
+        n = lim.step(dt, m)
+        assert int(n) == 3
+        lim.check(wait=True)
+        res.append(s.download())
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+    s = exa.AderDgSolver(dim, N, nc, dx=dx)
+    lim = exa.SubcellLimiter(s, capacity=2)
+    s.upload(u)
+    lim.step(dt, mask)
+    with pytest.raises(RuntimeError, match="capacity"):
+        lim.check(wait=True)
+    # the two cells that fit were limited, the third kept the DG result
+    s2 = exa.AderDgSolver(dim, N, nc, dx=dx); s2.upload(u); s2.step(dt)
+    a, b = s.download(), s2.download()
+    assert np.array_equal(a[3, 3], b[3, 3]) and np.array_equal(a[0, 0], res[0][0, 0]) and np.array_equal(a[2, 1], res[0][2, 1])
 
 
 @pytest.mark.gpu

@@ -1,12 +1,13 @@
-"""cfg 0 (plumbing, no GPU): the reference's example bodies run unchanged against the new
-KernelBuilder / TypedFunction and produce the state captured from the reference itself."""
+"""cfg 0 (plumbing, no GPU): the reference's example bodies, exec'ed where they lie under /root/reference
+(tests/ref_examples.py; skipped where the tree is absent), run unchanged against the new KernelBuilder /
+TypedFunction and produce the state captured from the reference itself."""
 import json
 import os
 
 import pytest
 import sympy
 
-from tests.example_kernels import batched_stateless, builder_state, kernel_generator
+from tests.ref_examples import (builder_state, reference_example, reference_example_3d_p15, rusanov_patch_update)
 
 
 def _golden(golden_dir, name):
@@ -14,9 +15,9 @@ def _golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,make", [
-    ("batched_stateless", lambda KB: batched_stateless(KB)),
-    ("kernel_generator", lambda KB: kernel_generator(KB)),
-    ("3d_p15", lambda KB: batched_stateless(KB, 3, 15, 1, 5, 0, 2)),
+    ("batched_stateless", lambda KB: reference_example("batched_stateless", KB)),
+    ("kernel_generator", lambda KB: reference_example("kernel_generator", KB)),
+    ("3d_p15", reference_example_3d_p15),
 ])
 def test_builder_state_equals_reference(golden_dir, name, make):
     from exahype_amd import KernelBuilder
@@ -82,23 +83,54 @@ def test_typed_function_semantics():
 
 
 def test_hip_printer_recognises_rusanov_shape_only():
+    """Recognition is structural (any names, dims, sizes); everything else raises -- no generic or CPU fallback."""
     from exahype_amd import KernelBuilder
     from exahype_amd.printers import HIPPrinter, UnrecognisedKernel
-    p = HIPPrinter(batched_stateless(KernelBuilder))
+    p = HIPPrinter(rusanov_patch_update(KernelBuilder, 2, 4, 1, 5, 5, 1))
     assert p.scheme == "fv-rusanov-faithful" and p.pde == 0 and "exa_fv_plan_create(dev, 0, 2, 4, 1, 5, 5, 1, 0" in p.code
+    assert "EulerRef2D" in p.code and "named Flux / maxEigenvalue / max" in p.code       # the chosen term set is on record
     # loop ranges of the generated reference kernel (Unit test/test.cpp:22-23, 81-82, 98-99)
     k = p.kernel()
     assert p.loop([k.LHS[2], k.RHS[2]], 1, 3, 0) == [(0, 1), (1, 5), (0, 6), (0, 1)]
     assert p.loop([k.LHS[11], k.RHS[11]], 1, 3, 1) == [(0, 1), (1, 5), (0, 6), (0, 1)]
     assert p.loop([k.LHS[13], k.RHS[13]], -1, 3, 2) == [(0, 1), (1, 5), (1, 5), (0, 10)]
-    p3 = HIPPrinter(batched_stateless(KernelBuilder, 3, 15, 1, 5, 0, 2))
+    p3 = HIPPrinter(rusanov_patch_update(KernelBuilder, 3, 15, 1, 5, 0, 2))
     assert p3.scheme == "fv-rusanov-faithful" and p3.pde == 1
-    with pytest.raises(UnrecognisedKernel):
-        HIPPrinter(kernel_generator(KernelBuilder))                 # Peano CellData flavour: no HIP kernel, says so
-    k2 = batched_stateless(KernelBuilder)
-    k2.single(k2.all_items['Q'][0], 2 * k2.all_items['Q_copy'][0])  # one extra statement -> not the known scheme
+    k2 = rusanov_patch_update(KernelBuilder, 2, 4, 1, 5, 5, 1)
+    k2.single(k2.all_items['U'][0], 2 * k2.all_items['W'][0])      # one extra statement -> not the known scheme
     with pytest.raises(UnrecognisedKernel):
         HIPPrinter(k2)
+
+
+def test_hip_printer_needs_to_know_the_pde_terms():
+    """The user's Flux / maxEigenvalue are opaque symbols (resolved at link time in the reference, Functions.h:2-4): only the
+    reference's own names select its Functions.cpp term set by default; any other system must say pde= or give bodies."""
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import HIPPrinter, UnrecognisedKernel
+    other = rusanov_patch_update(KernelBuilder, 2, 4, 1, 3, 0, 1, term_names=("swFlux", "swSpeed", "max"))
+    with pytest.raises(UnrecognisedKernel, match="pde="):
+        HIPPrinter(other)
+    assert HIPPrinter(other, pde="advection").pde == 2
+    with pytest.raises(UnrecognisedKernel, match="max"):            # the faithful kernel implements `max`, nothing else
+        HIPPrinter(rusanov_patch_update(KernelBuilder, 2, 4, 1, 5, 5, 1, term_names=("Flux", "maxEigenvalue", "min")))
+    k = KernelBuilder(3, 6, 0, 5, 0, n_patches=8)
+    k.item('u')
+    with pytest.raises(UnrecognisedKernel, match="pde="):           # an ADER-DG hint with no PDE information at all
+        HIPPrinter(k, scheme="aderdg")
+
+
+def test_hip_printer_rejects_reference_cell_data_flavour():
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import HIPPrinter, UnrecognisedKernel
+    with pytest.raises(UnrecognisedKernel):
+        HIPPrinter(reference_example("kernel_generator", KernelBuilder))   # Peano CellData flavour: no HIP kernel, says so
+
+
+def test_hip_printer_recognises_the_reference_example_itself():
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import HIPPrinter
+    p = HIPPrinter(reference_example("batched_stateless", KernelBuilder))
+    assert p.scheme == "fv-rusanov-faithful" and p.pde == 0
 
 
 def test_hip_printer_aderdg_hint_and_file(tmp_path):
@@ -106,21 +138,21 @@ def test_hip_printer_aderdg_hint_and_file(tmp_path):
     from exahype_amd.printers import HIPPrinter
     k = KernelBuilder(3, 6, 0, 5, 0, n_patches=8)
     k.item('u')
-    p = HIPPrinter(k, function_name="ader_step", scheme="aderdg")
+    p = HIPPrinter(k, function_name="ader_step", scheme="aderdg", pde="euler")
     assert p.grid == (2, 2, 2) and p.functionName() == "ader_step" and "dg_stage_a_kernel<3,6>" in p.code
     p.file(str(tmp_path / "plan.txt"))
     assert open(tmp_path / "plan.txt").read() == p.code
     with pytest.raises(ValueError):
-        HIPPrinter(KernelBuilder(3, 6, 1, 5, 0, 8), scheme="aderdg")       # a DG cell has no halo
+        HIPPrinter(KernelBuilder(3, 6, 1, 5, 0, 8), scheme="aderdg", pde="euler")       # a DG cell has no halo
     with pytest.raises(NotImplementedError):
         from exahype_amd.printers import MLIRPrinter
         MLIRPrinter(k)
 
 
 @pytest.mark.parametrize("name,make", [
-    ("batched_stateless", lambda KB: batched_stateless(KB)),
-    ("kernel_generator", lambda KB: kernel_generator(KB)),
-    ("3d_p15", lambda KB: batched_stateless(KB, 3, 15, 1, 5, 0, 2)),
+    ("batched_stateless", lambda KB: reference_example("batched_stateless", KB)),
+    ("kernel_generator", lambda KB: reference_example("kernel_generator", KB)),
+    ("3d_p15", reference_example_3d_p15),
 ])
 def test_cpp_printer_text_equals_reference(golden_dir, name, make):
     """the compatibility CPPPrinter reproduces the reference's generated text (HEAD)."""
@@ -135,7 +167,7 @@ def test_cpp_printer_text_equals_reference(golden_dir, name, make):
 def test_cpp_printer_file_prepends_includes(tmp_path):
     from exahype_amd import KernelBuilder
     from exahype_amd.printers import CPPPrinter
-    p = CPPPrinter(batched_stateless(KernelBuilder), function_name="step")
+    p = CPPPrinter(reference_example("batched_stateless", KernelBuilder), function_name="step")
     body = p.code
     assert body.startswith("void step(double* dt) {")
     p.file(str(tmp_path / "k.cpp"), header_file_name="Functions.h")
