@@ -72,7 +72,13 @@ def load(build_if_missing=True):
     except ImportError:
         pass
     from . import build as _build
-    if build_if_missing:
+    override = os.environ.get("EXA_LIB")                 # development aid: a variant build (exahype_amd.build --variant)
+    if override:
+        if not os.path.exists(override):
+            raise ExaHypeHipError(f"EXA_LIB={override} does not exist")
+        global LIB_PATH
+        LIB_PATH = override
+    elif build_if_missing:
         _build.build()                   # no-op when the library matches the sources (content stamp), else rebuilds
     elif not os.path.exists(LIB_PATH):
         raise ExaHypeHipError(f"{LIB_PATH} is missing (run `python -m exahype_amd.build`); there is no CPU fallback")

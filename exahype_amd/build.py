@@ -77,6 +77,28 @@ def _compile(unit, verbose):
     return obj
 
 
+def build_variant(tag, flags, jobs=None):
+    """Development aid: the library built with extra -D flags into lib/var_<tag>/ (never the one the product loads by
+    default; select it with EXA_LIB=<path>).  Used to time kernel variants side by side on one GPU box."""
+    global OBJ, COMMON
+    lib = os.path.join(HERE, "lib", "var_" + tag, "libexahype_hip.so")
+    saved = (OBJ, COMMON)
+    try:
+        OBJ = os.path.join(HERE, "_build", "var_" + tag)
+        COMMON = COMMON + list(flags)
+        os.makedirs(OBJ, exist_ok=True)
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+        with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+            objs = list(ex.map(lambda u: _compile(u, False), UNITS))
+        r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    finally:
+        OBJ, COMMON = saved
+    return lib
+
+
 def build(force=False, jobs=None, verbose=False):
     """Compile every unit (in parallel) and link the shared library; returns its path."""
     if not force and up_to_date():
@@ -100,5 +122,10 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--variant", metavar="TAG", help="development aid: build lib/var_TAG/ with the macros given by --define")
+    ap.add_argument("--define", action="append", default=[], metavar="MACRO", help="with --variant: -DMACRO (repeatable)")
     a = ap.parse_args()
-    print(build(a.force, a.jobs, a.verbose))
+    if a.variant:
+        print(build_variant(a.variant, ["-D" + d for d in a.define], a.jobs))
+    else:
+        print(build(a.force, a.jobs, a.verbose))

@@ -51,6 +51,47 @@ template <int N> __device__ inline const EXA_AS4 DgOps<N>* ops_here(const void* 
     return (const EXA_AS4 DgOps<N>*)a;
 }
 
+template <int N> struct DgStepOps;
+template <int N> __device__ inline const EXA_AS4 DgStepOps<N>* step_here(const void* raw) {
+    unsigned long long a = reinterpret_cast<unsigned long long>(raw);
+    asm volatile("" : "+s"(a));
+    return (const EXA_AS4 DgStepOps<N>*)a;
+}
+
+// K consecutive operator entries -> SGPRs, all requested in one batch and pinned there.  Scalar loads share the
+// lgkmcnt counter with the LDS and return out of order, so every wait for one is `s_waitcnt lgkmcnt(0)`: left to
+// itself the compiler fetched the rows just in time, between the LDS accesses of a phase -- three full drains per
+// pencil task and twelve per time update, each exposing the scalar-cache latency to a kernel with three waves per
+// SIMD.  One batch at the head of the phase, before its first LDS load, costs one wait.
+template <int K> __device__ inline void sload(const EXA_AS4 double* p, double (&d)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) d[k] = p[k];
+#pragma unroll
+    for (int k = 0; k + 3 < K; k += 4) asm volatile("" : "+s"(d[k]), "+s"(d[k + 1]), "+s"(d[k + 2]), "+s"(d[k + 3]));
+#pragma unroll
+    for (int k = K / 4 * 4; k < K; k++) asm volatile("" : "+s"(d[k]));
+}
+template <int K> __device__ inline void spin(double (&d)[K]) {     // values that are wave-uniform already (kernel arguments)
+#pragma unroll
+    for (int k = 0; k + 3 < K; k += 4) asm volatile("" : "+s"(d[k]), "+s"(d[k + 1]), "+s"(d[k + 2]), "+s"(d[k + 3]));
+#pragma unroll
+    for (int k = K / 4 * 4; k < K; k++) asm volatile("" : "+s"(d[k]));
+}
+
+// Operator entries that depend on dt: Tdt = -dt T, Tsdt = -dt Tsum, so that the time update is one FMA chain started
+// from u.  They live behind the operator image in HBM (dg_step_ops_kernel rewrites them in front of every stage-A
+// launch, stream-ordered) and reach the FMAs through scalar loads like the rest of the image -- as kernel arguments
+// the compiler kept all 84 SGPRs live across the kernel and spilled them to VGPR lanes.
+template <int N> struct DgStepOps {
+    double Tdt[N * N];
+    double Tsdt[N];
+};
+template <int N> __global__ void dg_step_ops_kernel(const DgOps<N>* __restrict__ ops, DgStepOps<N>* __restrict__ so, double dt) {
+    const int k = threadIdx.x;
+    if (k < N * N) so->Tdt[k] = -dt * ops->T[k];
+    if (k < N) so->Tsdt[k] = -dt * ops->Tsum[k];
+}
+
 // Diagnostic build only (-DEXA_STAMPS): per-phase cycle stamps of wave 0, summed into a debug
 // buffer of their own (never an output element); the production kernel executes no stamp.
 #ifdef EXA_STAMPS
@@ -114,6 +155,8 @@ __device__ unsigned long long g_exa_stamps[48];
 
 template <int DIM, int N, class PDE, int CPB> struct StageA {
     using G = Geo<DIM, N>;
+    // operator image in HBM: DgOps<N> | lane -> pencil tables (DIM * GW ints) | DgStepOps<N>
+    static constexpr size_t PERM_OFF = (sizeof(DgOps<N>) + 15) / 16 * 16;
     static constexpr int NV = PDE::NV;
     static constexpr int ASZ = NV * G::NTS * G::SL;         // one q-sized array
     static constexpr int CS = 3 * ASZ;                       // doubles per cell image: Q, A, B
@@ -121,6 +164,8 @@ template <int DIM, int N, class PDE, int CPB> struct StageA {
     static constexpr int TD = CPB * G::NN;                   // pencil tasks per direction (= node tasks)
     static constexpr int WPD = (TD + 63) / 64;               // waves per direction group
     static constexpr int NT = DIM * WPD * 64;                // threads per workgroup
+    static constexpr size_t STEP_OFF = (PERM_OFF + sizeof(int) * DIM * WPD * 64 + 15) / 16 * 16;
+    static constexpr size_t IMAGE_BYTES = STEP_OFF + sizeof(DgStepOps<N>);
 };
 
 // Cell image in LDS: three q-sized arrays Q | A | B, each SoA [var][time slab][node].
@@ -156,16 +201,27 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     const int bt = tid - grp * GW;                               // task index inside the group
     const double idx[3] = {idx0, idx1, idx2};
 
-    // ---- time-update role of this thread: node bt, the variables [v0, v1) of its direction group
-    // (the update is split by variable over the DIM groups, so all waves take part in it)
-    constexpr int NVA = (NV + DIM - 1) / DIM;                // variables per group
-    const bool t_task = bt < TD && grp * ((PDE::NV + DIM - 1) / DIM) < PDE::NV;   // groups without a variable sit the update out
+    // ---- time-update role of this thread: node bt, the variables of its direction group.  The update is split by
+    // variable over the DIM groups (all waves take part); the x group, which alone has the post-barrier store of its
+    // sums on its path, gets the smallest share (3-D Euler: x 1 variable, y and z 2 each).  Which variables a group owns
+    // is a compile-time property of the group (static_for over the groups, wave-uniform branch): straight-line code with
+    // constant LDS offsets.
+    constexpr int TBASE = NV / DIM, TREM = NV % DIM;
+    auto tcnt = [](int g) constexpr { return TBASE + (g >= DIM - TREM ? 1 : 0); };
+    auto tv0 = [](int g) constexpr { return g * TBASE + (g > DIM - TREM ? g - (DIM - TREM) : 0); };
+    constexpr int NVA = TBASE + (TREM ? 1 : 0);              // largest share
+    const bool t_node = bt < TD;
     const int tc = bt / NN, tn = bt - tc * NN;
     const int toff = tc * CS + G::node_off(tn);
-    const int v0 = grp * NVA < NV ? grp * NVA : NV, v1 = (grp + 1) * NVA < NV ? (grp + 1) * NVA : NV;
+#ifdef EXA_A_T_OLD
+    constexpr int NVA_OLD = (NV + DIM - 1) / DIM;            // variables per group
+    const bool t_task = bt < TD && grp * ((PDE::NV + DIM - 1) / DIM) < PDE::NV;
+    const int v0 = grp * NVA_OLD < NV ? grp * NVA_OLD : NV, v1 = (grp + 1) * NVA_OLD < NV ? (grp + 1) * NVA_OLD : NV;
+#endif
 
     // derivative-phase task of this lane (conflict-free enumeration built on the host: dg_inst.hip OpsImage), -1: none
-    const int d_task = grp < DIM ? reinterpret_cast<const int*>(static_cast<const char*>(ops_raw) + (sizeof(DgOps<N>) + 15) / 16 * 16)[grp * GW + bt] : -1;
+    const int d_task = grp < DIM ? reinterpret_cast<const int*>(static_cast<const char*>(ops_raw) + SA::PERM_OFF)[grp * GW + bt] : -1;
+    const void* step_raw = static_cast<const char*>(ops_raw) + SA::STEP_OFF;
 
     // Persistent grid: a workgroup walks over blocks of CPB cells (blk, blk + gridDim.x, ...) and fetches the next
     // block's u while it works on this one -- with one workgroup per CU (LDS) nothing else would hide that latency.
@@ -185,20 +241,29 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     {
         const long nblk = blk + gridDim.x;
         if (tid < CPB) cell_ids[par ^ 1][tid] = nblk < nblocks ? box.cell(nblk * CPB + tid) : -1;
-        if (t_task && n_it > 0) {                                // q_0 := u; level 0 only: iteration 0 reads nothing else, its update writes all
+#ifdef EXA_A_T_OLD
+        if (t_task && n_it > 0) {
 #pragma unroll
             for (int v = 0; v < NV; v++)
                 if (v >= v0 && v < v1) lds[toff + (v * NTS + 0) * SL] = ur[v];
         }
-    }
-    // A group with fewer than NVA variables repeats its last one (same lane, same values, same addresses; its loads are
-    // issued before the first copy's stores) instead of branching: the time update below is straight-line code, so the
-    // compiler can batch the scalar loads of T rows (a conditional per row pinned each s_load + s_waitcnt lgkmcnt(0)
-    // behind a branch).
-    double ur_mine[NVA];                                         // u of my variables (static register indices)
-    int v_mine[NVA];
+#else
+        if (t_node && n_it > 0) {                                // q_0 := u; level 0 only: iteration 0 reads nothing else, its update writes all
+            static_for<0, DIM>([&](auto gc) {
+                constexpr int GI = decltype(gc)::value;
+                if (grp == GI) {
 #pragma unroll
-    for (int vv = 0; vv < NVA; vv++) {
+                    for (int vv = 0; vv < tcnt(GI); vv++) lds[toff + ((tv0(GI) + vv) * NTS + 0) * SL] = ur[tv0(GI) + vv];
+                }
+            });
+        }
+#endif
+    }
+#ifdef EXA_A_T_OLD
+    double ur_mine[NVA_OLD];
+    int v_mine[NVA_OLD];
+#pragma unroll
+    for (int vv = 0; vv < NVA_OLD; vv++) {
         v_mine[vv] = (v0 + vv < v1) ? v0 + vv : (v1 > 0 ? v1 - 1 : 0);
         double x = 0.0;
 #pragma unroll
@@ -206,6 +271,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             if (v == v_mine[vv]) x = ur[v];
         ur_mine[vv] = x;
     }
+#endif
     __syncthreads();
     double un[NV];                                               // u of the next block's node, in flight during this block
     {
@@ -237,15 +303,24 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 const int l = it > 0 ? r / NF : 0, t = it > 0 ? r - l * NF : r;
                 if constexpr (D == 0) did_x = true;
                 const int off = c * CS + l * SL + G::pbase(D, t);
-#pragma unroll
-                for (int i = 0; i < N; i++)
-#pragma unroll
-                    for (int v = 0; v < NV; v++) s[i][v] = 0.0;
+                // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs --
+                // s_i -+ s_{N-1-i} from F_j +- F_{N-1-j}; odd N: the middle node and the middle row on top.
+                // (tried in round 2, measured and left as opt-in macros: the whole operator in SGPRs first -- one batch, one
+                // wait -- and every LDS load of the pencil issued before the first flux; both lose to the form below, whose
+                // waits hide behind the other two waves of the SIMD)
+                constexpr int H = N / 2;
+                constexpr int NE = H * N + H + 1;
+#ifndef EXA_A_SLOAD_D
+                const EXA_AS4 double* Em = ops_here<N>(ops_raw)->DEO;
+#else                // measured 2.5 % slower at N = 6 (profiles/r02_stage_a_variants.txt): 44 more live SGPRs, the waits were hidden
+                double Em[NE];
+                sload<NE>(ops_here<N>(ops_raw)->DEO, Em);
+#endif
                 // pencils along the contiguous axis (ps == 1, N even): 16-byte LDS accesses -- the pencil
                 // bases are 3*t 16-byte units apart, a permutation mod 16 for every hardware lane group, so
                 // ds_read_b128 / ds_write_b128 are conflict-free where 8-byte accesses are 2-way conflicted
                 constexpr bool WIDE = (ps == 1) && (N % 2 == 0);
-                double qw[WIDE ? N : 1][NV];
+                double qw[N][NV];
                 if constexpr (WIDE) {
 #pragma unroll
                     for (int v = 0; v < NV; v++)
@@ -255,12 +330,19 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             qw[2 * jj][v] = t2.x;
                             qw[2 * jj + 1][v] = t2.y;
                         }
+                } else {
+#ifdef EXA_A_LOADS_FIRST   // (every load of the pencil first: 0.5 % slower at N = 6, more live registers)
+                    // in the order the even-odd form consumes them: node j, its mirror, next j
+#pragma unroll
+                    for (int j = 0; j < (N + 1) / 2; j++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            qw[j][v] = EXA_LD(off + v * NTS * SL + j * ps);
+                            if (j != N - 1 - j) qw[N - 1 - j][v] = EXA_LD(off + v * NTS * SL + (N - 1 - j) * ps);
+                        }
+#endif
                 }
                 {
-                    // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs --
-                    // s_i -+ s_{N-1-i} from F_j +- F_{N-1-j}; odd N: the middle node and the middle row on top
-                    constexpr int H = N / 2;
-                    const EXA_AS4 double* Em = ops_here<N>(ops_raw)->DEO;
                     double P[H > 0 ? H : 1][NV], M[H > 0 ? H : 1][NV], mid[NV];
 #pragma unroll
                     for (int i = 0; i < H; i++)
@@ -271,16 +353,20 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 #pragma unroll
                     for (int j = 0; j < H; j++) {
                         const int jm = N - 1 - j;                // mirror node
-                        double qa[NV], aa[NA], qb[NV], ab[NA], Fa[NV], Fb[NV];
+                        double aa[NA], ab[NA], Fa[NV], Fb[NV];
+#ifndef EXA_A_LOADS_FIRST
+                        if constexpr (!WIDE) {
 #pragma unroll
-                        for (int v = 0; v < NV; v++) {
-                            qa[v] = WIDE ? qw[WIDE ? j : 0][v] : EXA_LD(off + v * NTS * SL + j * ps);
-                            qb[v] = WIDE ? qw[WIDE ? jm : 0][v] : EXA_LD(off + v * NTS * SL + jm * ps);
+                            for (int v = 0; v < NV; v++) {
+                                qw[j][v] = EXA_LD(off + v * NTS * SL + j * ps);
+                                qw[jm][v] = EXA_LD(off + v * NTS * SL + jm * ps);
+                            }
                         }
-                        PDE::aux_fast(qa, aa);
-                        PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
-                        PDE::aux_fast(qb, ab);
-                        PDE::template flux_scaled<D>(qb, ab, idx[D], Fb);
+#endif
+                        PDE::aux_fast(qw[j], aa);
+                        PDE::template flux_scaled<D>(qw[j], aa, idx[D], Fa);
+                        PDE::aux_fast(qw[jm], ab);
+                        PDE::template flux_scaled<D>(qw[jm], ab, idx[D], Fb);
 #pragma unroll
                         for (int v = 0; v < NV; v++) {
                             const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
@@ -303,11 +389,15 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         }
                     }
                     if constexpr (N % 2 == 1) {                  // middle node
-                        double qa[NV], aa[NA], Fa[NV];
+                        double aa[NA], Fa[NV];
+#ifndef EXA_A_LOADS_FIRST
+                        if constexpr (!WIDE) {
 #pragma unroll
-                        for (int v = 0; v < NV; v++) qa[v] = EXA_LD(off + v * NTS * SL + H * ps);
-                        PDE::aux_fast(qa, aa);
-                        PDE::template flux_scaled<D>(qa, aa, idx[D], Fa);
+                            for (int v = 0; v < NV; v++) qw[H][v] = EXA_LD(off + v * NTS * SL + H * ps);
+                        }
+#endif
+                        PDE::aux_fast(qw[H], aa);
+                        PDE::template flux_scaled<D>(qw[H], aa, idx[D], Fa);
 #pragma unroll
                         for (int i = 0; i < H; i++) {
                             const double ec = Em[H * N + i];
@@ -342,6 +432,110 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 }
             }
         });
+#ifndef EXA_A_T_OLD
+        EXA_STAMP(1);
+        __syncthreads();                                             // (1) every read of Q is done; S_y (A) and S_z (B) are complete
+        EXA_STAMP(2);
+        // ---- time update, one straight-line copy per direction group (wave-uniform branch: every wave of the workgroup
+        // runs exactly one copy, each copy contains barrier (2) once).  Between barriers (1) and (2) the x group writes
+        // its sums over Q (dead now) while everybody already fetches S_y + S_z of its own variables, so that after (2)
+        // only S_x is left to load.
+        static_for<0, DIM>([&](auto gc) {
+            constexpr int GI = decltype(gc)::value;
+            constexpr int CNT = tcnt(GI), V0 = tv0(GI);
+            if (grp == GI) {
+                if constexpr (GI == 0) {
+                    if (did_x) {                                     // Q := S_x
+                        constexpr int ps = G::pstride(0);
+#pragma unroll
+                        for (int i = 0; i < N; i++)
+#pragma unroll
+                            for (int v = 0; v < NV; v++) EXA_ST(zoff + v * NTS * SL + i * ps, s[i][v]);
+                    }
+                }
+#ifndef EXA_ABL_SKIP_T
+                if (it == 0) {                                       // the iterate was constant in time: level 0, row sums of T
+                    double Syz0[CNT > 0 ? CNT : 1];
+                    if (t_node) {
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++) {
+                            const int o = toff + ((V0 + vv) * NTS + 0) * SL;
+                            double x = EXA_LD(o + ASZ);
+                            if constexpr (DIM == 3) x += EXA_LD(o + 2 * ASZ);
+                            Syz0[vv] = x;
+                        }
+                    }
+                    __syncthreads();                                 // (2) S_x is in Q
+                    if (t_node && CNT > 0) {
+                        double Ts[N];
+                        sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++) {
+                            const int o = toff + ((V0 + vv) * NTS + 0) * SL;
+                            const double x = EXA_LD(o) + Syz0[vv];
+                            const double uv = ur[V0 + vv];
+#pragma unroll
+                            for (int lp = 0; lp < N; lp++) EXA_ST(toff + ((V0 + vv) * NTS + lp) * SL, fma(Ts[lp], x, uv));
+                        }
+                    }
+                } else {
+                    double S[CNT > 0 ? CNT : 1][N];
+                    if (t_node) {
+                        double Sz[CNT > 0 ? CNT : 1][N];             // every load first, then the adds
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++)
+#pragma unroll
+                            for (int l = 0; l < N; l++) {
+                                const int o = toff + ((V0 + vv) * NTS + l) * SL;
+                                S[vv][l] = EXA_LD(o + ASZ);
+                                if constexpr (DIM == 3) Sz[vv][l] = EXA_LD(o + 2 * ASZ);
+                            }
+                        if constexpr (DIM == 3) {
+#pragma unroll
+                            for (int vv = 0; vv < CNT; vv++)
+#pragma unroll
+                                for (int l = 0; l < N; l++) S[vv][l] += Sz[vv][l];
+                        }
+                    }
+                    __syncthreads();                                 // (2) S_x is in Q
+                    if (t_node && CNT > 0) {
+                        double Sx[CNT > 0 ? CNT : 1][N];
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++)
+#pragma unroll
+                            for (int l = 0; l < N; l++) Sx[vv][l] = EXA_LD(toff + ((V0 + vv) * NTS + l) * SL);
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++)
+#pragma unroll
+                            for (int l = 0; l < N; l++) S[vv][l] += Sx[vv][l];
+                        // -dt T, half of its rows at a time (N*N/2 doubles in SGPRs: the whole matrix next to the phase's
+                        // other scalars would spill), each half serving every variable
+                        constexpr int RH = (N + 1) / 2;
+                        static_for<0, 2>([&](auto hc) {
+                            constexpr int half = decltype(hc)::value;
+                            constexpr int R0 = half * RH, RN = (half == 0) ? RH : N - RH;
+                            double Tm[RN * N];
+                            sload<RN * N>(step_here<N>(step_raw)->Tdt + R0 * N, Tm);
+#pragma unroll
+                            for (int vv = 0; vv < CNT; vv++) {
+                                const double uv = ur[V0 + vv];
+#pragma unroll
+                                for (int r = 0; r < RN; r++) {
+                                    double acc = uv;
+#pragma unroll
+                                    for (int l = 0; l < N; l++) EXA_FMA(acc, Tm[r * N + l], S[vv][l]);
+                                    EXA_ST(toff + ((V0 + vv) * NTS + R0 + r) * SL, acc);
+                                }
+                            }
+                        });
+                    }
+                }
+#else
+                __syncthreads();
+#endif
+            }
+        });
+#else
         EXA_STAMP(1);
         __syncthreads();
         EXA_STAMP(2);
@@ -362,7 +556,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         if (t_task && it == 0) {
             const EXA_AS4 double* Ts = ops_here<N>(ops_raw)->Tsum;        // row sums of T
 #pragma unroll
-            for (int vv = 0; vv < NVA; vv++) {
+            for (int vv = 0; vv < NVA_OLD; vv++) {
                 if (v0 + vv < v1) {
                     const int o = toff + ((v0 + vv) * NTS + 0) * SL;
                     double x = EXA_LD(o) + EXA_LD(o + ASZ);
@@ -388,14 +582,14 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             };
             issue(0);
 #pragma unroll
-            for (int vv = 0; vv < NVA; vv++) {
+            for (int vv = 0; vv < NVA_OLD; vv++) {
                 double S[N];
 #pragma unroll
                 for (int l = 0; l < N; l++) {
                     S[l] = Sa[l] + Sb[l];
                     if constexpr (DIM == 3) S[l] += Sc[l];
                 }
-                if (vv + 1 < NVA) issue(vv + 1);
+                if (vv + 1 < NVA_OLD) issue(vv + 1);
                 const double uv = ur_mine[vv];
 #pragma unroll
                 for (int lp = 0; lp < N; lp++) {
@@ -407,8 +601,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             }
         }
 #endif
+#endif
         EXA_STAMP(3);
-        __syncthreads();
+        __syncthreads();                                             // (3) the new iterate is in Q
         EXA_STAMP(4);
     }
 

@@ -177,6 +177,29 @@ struct Euler {
         const double un = (d == 0 ? q[1] : (d == 1 ? q[2] : q[3])) * irho;
         return fmax(fabs(un - c), fabs(un + c));
     }
+    // Per-volume scalars for the FV patch kernels (corrected Rusanov): every volume's flux and eigenvalue are needed by
+    // its own update and by its 2*dim neighbours', so 1/rho, p and the sound speed are computed ONCE per volume (fast
+    // reciprocal / square root: <= 1e-15 relative, tolerance 1e-10) and kept beside the state.
+    static constexpr int NFVAUX = 3;
+    __device__ static inline void fv_aux(const double* q, double* a) {
+        const double irho = fast_rcp(q[0]);
+        const double p = (GAMMA - 1) * (q[4] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+        a[0] = irho;
+        a[1] = p;
+        a[2] = fast_sqrt(GAMMA * fabs(p) * fabs(irho));
+    }
+    template <int D> __device__ static inline void flux_fv(const double* q, const double* a, double* F) {
+        const double coeff = a[0] * q[D + 1];
+        F[0] = coeff * q[0];
+        F[1] = coeff * q[1];
+        F[2] = coeff * q[2];
+        F[3] = coeff * q[3];
+        F[4] = coeff * q[4] + coeff * a[1];
+        F[D + 1] += a[1];
+    }
+    template <int D> __device__ static inline double maxeig_fv(const double* q, const double* a) {
+        return fabs(q[D + 1] * a[0]) + a[2];              // max(|u_n - c|, |u_n + c|) = |u_n| + c
+    }
 };
 
 // Linear advection of NVARS variables with a fixed velocity (known-answer tests).

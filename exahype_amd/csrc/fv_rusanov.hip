@@ -17,6 +17,7 @@
 //   is bit-identical to the g++ build of the reference wherever that is defined.
 // MODE 1 (corrected Rusanov): dt/h, all n_real variables.
 #include <cstdio>
+#include <type_traits>
 #include "exa_launch.hpp"
 #include "exa_pde.hpp"
 #ifdef EXA_USER_PDE_HEADER
@@ -27,6 +28,13 @@ namespace exa {
 
 constexpr int MAXV = 8;
 typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <int I, int E, class F> __device__ inline void static_for_fv(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for_fv<I + 1, E>(f);
+    }
+}
 
 // STAGE = true (small patches): the workgroup's `ppb` patches are one contiguous block of HBM; it is
 // copied into LDS with coalesced 16-byte loads and the stencil reads LDS (the AoS stencil reads straight
@@ -215,104 +223,322 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
 }
 
 // Large 3-D patches (cfg 4's limiter patch: 17^3 x 5 doubles = 196 KB with halo, more than LDS): the patch streams
-// plane by plane (axis 0) through a 4-slot LDS ring, filled with coalesced 16-byte loads one plane ahead; thread
-// (j, k) updates the volume (i, j, k) of the current plane from the ring.  The ring holds the OLD values, so the new
-// values of plane i go straight back to HBM in place: every plane is read once and its interior written once.
-template <class PDE, int MODE>
-__global__ void __launch_bounds__(256)
+// plane by plane (axis 0) through a 3-slot LDS ring; thread (j, k) updates the volume (i, j, k) of the current plane
+// and keeps its own column (i-1, i, i+1) in registers, so the ring only has to hold planes i and i+1 plus the slot
+// plane i+2 lands in: 35 KB per workgroup (49 KB with the cached scalars) -> three workgroups per CU.
+//
+// Data movement (what bounds the kernel): plane i+2 is fetched into REGISTERS at the top of iteration i (16-byte
+// global loads wherever the 8-byte-aligned plane allows: planes of S*S*V = 1445 doubles alternate between 16-byte
+// aligned and not) and written to its ring slot during the update of plane i, so a whole iteration hides its latency.
+// Results do not go back volume by volume (V = 5 doubles at a 40-byte stride: partial lines): once every stencil read
+// of plane i is done (barrier) they overwrite plane i's ring slot, whose rows j in [H, P+H) are ONE contiguous block
+// of P*S*V doubles in HBM (the k-halo volumes of a row keep their old values) and stream out with coalesced 16-byte
+// stores.
+//
+// Arithmetic (CACHE: corrected mode of a PDE with the fv_aux interface): 1/rho, p and the sound speed are computed
+// once per volume when its plane arrives and kept in a 2-plane LDS ring beside the state -- the seven stencil visits
+// of a volume no longer repeat two IEEE divisions and a square root each (13 divisions + 7 square roots per volume
+// before) -- and the x-face flux of the previous plane is reused.  Faithful mode keeps the reference's arithmetic
+// untouched (bit-exact), only the data movement is shared.
+template <class P, class = void> struct has_fv_cache : std::false_type {};
+template <class P> struct has_fv_cache<P, std::void_t<decltype(P::NFVAUX)>> : std::true_type {};
+
+constexpr int SLAB_NT = 256;
+constexpr int SLAB_NR = 4;          // double2 per thread that hold a plane in flight (<= 2048 doubles per plane)
+__host__ __device__ constexpr size_t slab_lds_bytes(int S, int V, bool cache) {
+    return ((size_t)3 * S * S * V + (cache ? (size_t)2 * S * S * 3 : 0)) * sizeof(double);
+}
+
+template <class PDE, int MODE, bool CACHE>
+__global__ void __launch_bounds__(SLAB_NT, 2)
 fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h,
                        const long* __restrict__ slot) {
     extern __shared__ __attribute__((aligned(16))) double ring[];
     if (slot && slot[blockIdx.x] < 0) return;                      // patch not in use (workgroup-uniform)
+    constexpr int NA = CACHE ? 3 : 1;
+    constexpr int NQ = CACHE ? PDE::NV : MAXV;                    // state entries kept per volume (cached variant: m == NV)
     const int S = P + 2 * H;
     const int plane = S * S * V;                                  // doubles per plane
+    const int aplane = S * S * NA;
+    double* auxr = ring + 3 * plane;                              // [2][S*S][NA]   (CACHE only)
+    const int orow = S * V;
     double* Qp = Q + (long)blockIdx.x * S * plane;
     const int tid = threadIdx.x;
     const int j = tid / P + H, k = tid % P + H;
     const bool cell_ok = tid < P * P;
-    auto load_plane = [&](int i) {
+    const int x = cell_ok ? j * S + k : S + 1;                     // volume index inside a plane (idle lanes: a valid one)
+
+    // ---- plane i -> registers (issue) / registers -> ring slot (land)
+    v2d hold[SLAB_NR];
+    double hold_head = 0.0, hold_tail = 0.0;
+    auto issue = [&](int i) {
         const double* src = Qp + (long)i * plane;
-        double* dst = ring + (i & 3) * plane;
-        if (((reinterpret_cast<unsigned long long>(src) & 15) == 0) && (plane % 2 == 0)) {
-            for (int x = tid; x < plane / 2; x += 256) reinterpret_cast<double2*>(dst)[x] = reinterpret_cast<const double2*>(src)[x];
-        } else {
-            for (int x = tid; x < plane; x += 256) dst[x] = src[x];
+        const int head = (int)((reinterpret_cast<unsigned long long>(src) >> 3) & 1);   // first double not 16-byte aligned
+        const int npair = (plane - head) >> 1;
+        const v2d* s2 = reinterpret_cast<const v2d*>(src + head);
+        // unconditional loads at clamped (in-bounds) indices: a load under a lane condition becomes a branch with its own
+        // s_waitcnt vmcnt(0) (and here a scratch spill) -- the requests would go out one at a time
+#pragma unroll
+        for (int r = 0; r < SLAB_NR; r++) {
+            const int xx = tid + r * SLAB_NT;
+            hold[r] = s2[xx < npair ? xx : npair - 1];
+        }
+        hold_head = src[0];
+        hold_tail = src[plane - 1];
+    };
+    auto land = [&](int i) {
+        const double* src = Qp + (long)i * plane;
+        const int head = (int)((reinterpret_cast<unsigned long long>(src) >> 3) & 1);
+        const int npair = (plane - head) >> 1;
+        double* dst = ring + (i % 3) * plane;
+#pragma unroll
+        for (int r = 0; r < SLAB_NR; r++) {
+            const int xx = tid + r * SLAB_NT;
+            if (xx < npair) {
+                dst[head + 2 * xx] = hold[r].x;
+                dst[head + 2 * xx + 1] = hold[r].y;
+            }
+        }
+        if (tid == 0 && head) dst[0] = hold_head;
+        if (tid == 1 && ((plane - head) & 1)) dst[plane - 1] = hold_tail;
+    };
+    // per-volume scalars of plane i (every volume of the plane, halo included: the neighbours read them)
+    auto make_aux = [&](int i) {
+        if constexpr (CACHE) {
+            const double* src = ring + (i % 3) * plane;
+            double* dst = auxr + (i & 1) * aplane;
+            for (int xx = tid; xx < S * S; xx += SLAB_NT) {
+                double q[PDE::NV], a[3];
+#pragma unroll
+                for (int v = 0; v < PDE::NV; v++) q[v] = src[xx * V + v];
+                PDE::fv_aux(q, a);
+                dst[xx * 3 + 0] = a[0];
+                dst[xx * 3 + 1] = a[1];
+                dst[xx * 3 + 2] = a[2];
+            }
         }
     };
-    load_plane(H - 1);
-    load_plane(H);
-    for (int i = H; i < P + H; i++) {
-        load_plane(i + 1);                                         // slot (i+1)&3 was last read in iteration i-3
-        __syncthreads();
-        if (cell_ok) {
-            const double* c0 = ring + (i & 3) * plane + (j * S + k) * V;
-            const double* nb[3][2] = {{ring + ((i - 1) & 3) * plane + (j * S + k) * V, ring + ((i + 1) & 3) * plane + (j * S + k) * V},
-                                      {c0 - S * V, c0 + S * V}, {c0 - V, c0 + V}};
-            const int co[3] = {i, j, k};
-            double qc[MAXV], out[MAXV];
+
+    // rolling column of this lane: states (and scalars) of (i-1, j, k), (i, j, k); x-face flux between them
+    double qm[NQ], qc[NQ], qp[NQ], am[NA], ac[NA], Fxl[NQ];
 #pragma unroll
-            for (int v = 0; v < MAXV; v++) qc[v] = v < m ? c0[v] : 0.0;
-            if constexpr (MODE == 0) {
-                double acc[MAXV];
+    for (int v = 0; v < NQ; v++) { qm[v] = 0.0; qc[v] = 0.0; qp[v] = 0.0; Fxl[v] = 0.0; }
 #pragma unroll
-                for (int v = 0; v < MAXV; v++) acc[v] = qc[v];
+    for (int a = 0; a < NA; a++) { am[a] = 0.0; ac[a] = 0.0; }
+
+    // ---- prologue: plane H-1 -> column registers; planes H, H+1 in the ring; plane H+2 requested inside the loop.
+    // The first two planes are requested together (the second through a register set that is dead afterwards).
+    {
+        const double* src = Qp + (long)H * plane;
+        const int head = (int)((reinterpret_cast<unsigned long long>(src) >> 3) & 1);
+        const int npair = (plane - head) >> 1;
+        const v2d* s2 = reinterpret_cast<const v2d*>(src + head);
+        v2d h2[SLAB_NR];
+        issue(H - 1);
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    double Fp[MAXV], Fm[MAXV], qP[MAXV], qM[MAXV];
-#pragma unroll
-                    for (int v = 0; v < MAXV; v++) { Fp[v] = 0.0; Fm[v] = 0.0; qP[v] = v < m ? nb[d][1][v] : 0.0; qM[v] = v < m ? nb[d][0][v] : 0.0; }
-                    if (co[d] + 1 < P + H) PDE::flux_rt(qP, d, Fp);
-                    if (co[d] - 1 >= H) PDE::flux_rt(qM, d, Fm);
-#pragma unroll
-                    for (int v = 0; v < MAXV; v++) acc[v] = acc[v] - 0.5 * Fp[v] + 0.5 * Fm[v];
-                }
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    double qP[MAXV], qM[MAXV];
-#pragma unroll
-                    for (int v = 0; v < MAXV; v++) { qP[v] = v < m ? nb[d][1][v] : 0.0; qM[v] = v < m ? nb[d][0][v] : 0.0; }
-                    const double lc = PDE::maxeig(qc, d);
-                    const double lp = (co[d] + 1 < P + H) ? PDE::maxeig(qP, d) : 0.0;
-                    const double lm = (co[d] - 1 >= H) ? PDE::maxeig(qM, d) : 0.0;
-                    const double mp = lp > lc ? lp : lc;
-                    const double mm = lm > lc ? lm : lc;
-                    acc[0] = 0.5 * dt * ((-qP[0] + qc[0]) * mp + (qM[0] - qc[0]) * mm) + acc[0];
-                }
-#pragma unroll
-                for (int v = 0; v < MAXV; v++) out[v] = acc[v];
-            } else {
-                double acc[MAXV];
-#pragma unroll
-                for (int v = 0; v < MAXV; v++) acc[v] = 0.0;
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    double qpp[MAXV], qmp[MAXV], Fc[MAXV], Fn[MAXV];
-#pragma unroll
-                    for (int v = 0; v < MAXV; v++) { qpp[v] = v < m ? nb[d][1][v] : 0.0; qmp[v] = v < m ? nb[d][0][v] : 0.0; Fc[v] = 0.0; Fn[v] = 0.0; }
-                    const double lc = PDE::maxeig(qc, d);
-                    const double sp = fmax(lc, PDE::maxeig(qpp, d));
-                    const double sm = fmax(PDE::maxeig(qmp, d), lc);
-                    PDE::flux_rt(qc, d, Fc);
-                    PDE::flux_rt(qpp, d, Fn);
-#pragma unroll
-                    for (int v = 0; v < MAXV; v++)
-                        if (v < m) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sp * (qpp[v] - qc[v]);
-#pragma unroll
-                    for (int v = 0; v < MAXV; v++) Fn[v] = 0.0;
-                    PDE::flux_rt(qmp, d, Fn);
-#pragma unroll
-                    for (int v = 0; v < MAXV; v++)
-                        if (v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qmp[v]);
-                }
-#pragma unroll
-                for (int v = 0; v < MAXV; v++) out[v] = qc[v] - dt_over_h * acc[v];
-            }
-            double* dst = Qp + (long)i * plane + (j * S + k) * V;
-#pragma unroll
-            for (int v = 0; v < MAXV; v++)
-                if (v < m) dst[v] = out[v];
+        for (int r = 0; r < SLAB_NR; r++) {
+            const int xx = tid + r * SLAB_NT;
+            h2[r] = s2[xx < npair ? xx : npair - 1];
         }
-        __syncthreads();                                           // plane i-1's slot may be refilled next iteration
+        const double h2_head = src[0], h2_tail = src[plane - 1];
+        land(H - 1);
+        double* dst = ring + (H % 3) * plane;
+#pragma unroll
+        for (int r = 0; r < SLAB_NR; r++) {
+            const int xx = tid + r * SLAB_NT;
+            if (xx < npair) {
+                dst[head + 2 * xx] = h2[r].x;
+                dst[head + 2 * xx + 1] = h2[r].y;
+            }
+        }
+        if (tid == 0 && head) dst[0] = h2_head;
+        if (tid == 1 && ((plane - head) & 1)) dst[plane - 1] = h2_tail;
+    }
+    issue(H + 1);
+    __syncthreads();
+    make_aux(H - 1);
+    make_aux(H);
+    {
+        const double* r0 = ring + ((H - 1) % 3) * plane + x * V;
+        const double* r1 = ring + (H % 3) * plane + x * V;
+#pragma unroll
+        for (int v = 0; v < NQ; v++) { qm[v] = (CACHE || v < m) ? r0[v] : 0.0; qc[v] = (CACHE || v < m) ? r1[v] : 0.0; }
+    }
+    __syncthreads();                                               // scalars visible; every lane has read plane H-1
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { am[a] = auxr[((H - 1) & 1) * aplane + x * 3 + a]; ac[a] = auxr[(H & 1) * aplane + x * 3 + a]; }
+        // x-face flux between planes H-1 and H:  F* = 1/2 (f(L) + f(R)) - 1/2 s (R - L)
+        double FL[PDE::NV], FR[PDE::NV];
+        PDE::template flux_fv<0>(qm, am, FL);
+        PDE::template flux_fv<0>(qc, ac, FR);
+        const double sxl = fmax(PDE::template maxeig_fv<0>(qm, am), PDE::template maxeig_fv<0>(qc, ac));
+#pragma unroll
+        for (int v = 0; v < PDE::NV; v++) Fxl[v] = 0.5 * (FL[v] + FR[v]) - 0.5 * sxl * (qc[v] - qm[v]);
+    }
+    land(H + 1);                                                   // slot of plane H-2 == slot (H+1) % 3: nothing lives there yet
+    __syncthreads();                                               // plane H+1 in the ring (the scalars of H-1 are in registers now)
+
+    for (int i = H; i < P + H; i++) {
+        // ---- stage 1: request plane i+2 (stays in registers during the update); scalars of plane i+1
+        const bool more = i + 2 <= P + H;                          // planes H-1 .. P+H are all the stencil reads
+        if (more) issue(i + 2);
+        make_aux(i + 1);                                           // aux slot (i+1)&1 held plane i-1: in registers since iteration i-1
+        __syncthreads();                                           // (A) scalars of i+1 visible; the rows of plane i-1 have left LDS
+        // ---- stage 2: update volume (i, j, k) in registers
+        double out[NQ];
+        {
+            const double* rc = ring + (i % 3) * plane;
+            const double* rp = ring + ((i + 1) % 3) * plane;
+#pragma unroll
+            for (int v = 0; v < NQ; v++) qp[v] = (CACHE || v < m) ? rp[x * V + v] : 0.0;
+            if constexpr (CACHE) {
+                const double* ap = auxr + ((i + 1) & 1) * aplane;
+                const double* acp = auxr + (i & 1) * aplane;
+                double app[3], acc[PDE::NV];
+#pragma unroll
+                for (int a = 0; a < 3; a++) app[a] = ap[x * 3 + a];
+                // x: low face from the previous iteration, high face now (kept for the next one)
+                {
+                    double FL[PDE::NV], FR[PDE::NV];
+                    PDE::template flux_fv<0>(qc, ac, FL);
+                    PDE::template flux_fv<0>(qp, app, FR);
+                    const double sh = fmax(PDE::template maxeig_fv<0>(qc, ac), PDE::template maxeig_fv<0>(qp, app));
+#pragma unroll
+                    for (int v = 0; v < PDE::NV; v++) {
+                        const double Fh = 0.5 * (FL[v] + FR[v]) - 0.5 * sh * (qp[v] - qc[v]);
+                        acc[v] = Fh - Fxl[v];
+                        Fxl[v] = Fh;
+                    }
+                }
+                static_for_fv<1, 3>([&](auto dc) {
+                    constexpr int D = decltype(dc)::value;
+                    const int st = (D == 1) ? S : 1;
+                    double qn[PDE::NV], an[3], Fc[PDE::NV], Fn[PDE::NV];
+                    PDE::template flux_fv<D>(qc, ac, Fc);
+                    const double lc = PDE::template maxeig_fv<D>(qc, ac);
+#pragma unroll
+                    for (int sgn = 0; sgn < 2; sgn++) {
+                        const int xn = sgn ? x + st : x - st;
+#pragma unroll
+                        for (int v = 0; v < PDE::NV; v++) qn[v] = rc[xn * V + v];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) an[a] = acp[xn * 3 + a];
+                        PDE::template flux_fv<D>(qn, an, Fn);
+                        const double sf = fmax(lc, PDE::template maxeig_fv<D>(qn, an));
+#pragma unroll
+                        for (int v = 0; v < PDE::NV; v++) {
+                            if (sgn) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sf * (qn[v] - qc[v]);
+                            else acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sf * (qc[v] - qn[v]);
+                        }
+                    }
+                });
+#pragma unroll
+                for (int v = 0; v < PDE::NV; v++) out[v] = qc[v] - dt_over_h * acc[v];
+#pragma unroll
+                for (int a = 0; a < 3; a++) { am[a] = ac[a]; ac[a] = app[a]; }
+            } else {
+                const double* c0 = rc + x * V;
+                const int co[3] = {i, j, k};
+                // neighbour states: axis 0 from the column registers, axes 1 and 2 from the ring
+                double qN[3][2][MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) {
+                    qN[0][0][v] = qm[v];
+                    qN[0][1][v] = qp[v];
+                    qN[1][0][v] = v < m ? c0[v - S * V] : 0.0;
+                    qN[1][1][v] = v < m ? c0[v + S * V] : 0.0;
+                    qN[2][0][v] = v < m ? c0[v - V] : 0.0;
+                    qN[2][1][v] = v < m ? c0[v + V] : 0.0;
+                }
+                if constexpr (MODE == 0) {
+                    double acc[MAXV];
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) acc[v] = qc[v];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        double Fp[MAXV], Fm[MAXV];
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++) { Fp[v] = 0.0; Fm[v] = 0.0; }
+                        if (co[d] + 1 < P + H) PDE::flux_rt(qN[d][1], d, Fp);
+                        if (co[d] - 1 >= H) PDE::flux_rt(qN[d][0], d, Fm);
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++) acc[v] = acc[v] - 0.5 * Fp[v] + 0.5 * Fm[v];
+                    }
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        const double lc = PDE::maxeig(qc, d);
+                        const double lp = (co[d] + 1 < P + H) ? PDE::maxeig(qN[d][1], d) : 0.0;
+                        const double lm = (co[d] - 1 >= H) ? PDE::maxeig(qN[d][0], d) : 0.0;
+                        const double mp = lp > lc ? lp : lc;
+                        const double mm = lm > lc ? lm : lc;
+                        acc[0] = 0.5 * dt * ((-qN[d][1][0] + qc[0]) * mp + (qN[d][0][0] - qc[0]) * mm) + acc[0];
+                    }
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) out[v] = acc[v];
+                } else {
+                    double acc[MAXV];
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) acc[v] = 0.0;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        double Fc[MAXV], Fn[MAXV];
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++) { Fc[v] = 0.0; Fn[v] = 0.0; }
+                        const double lc = PDE::maxeig(qc, d);
+                        const double sp = fmax(lc, PDE::maxeig(qN[d][1], d));
+                        const double sm = fmax(PDE::maxeig(qN[d][0], d), lc);
+                        PDE::flux_rt(qc, d, Fc);
+                        PDE::flux_rt(qN[d][1], d, Fn);
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++)
+                            if (v < m) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sp * (qN[d][1][v] - qc[v]);
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++) Fn[v] = 0.0;
+                        PDE::flux_rt(qN[d][0], d, Fn);
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++)
+                            if (v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qN[d][0][v]);
+                    }
+#pragma unroll
+                    for (int v = 0; v < MAXV; v++) out[v] = qc[v] - dt_over_h * acc[v];
+                }
+            }
+            // shift the column
+#pragma unroll
+            for (int v = 0; v < NQ; v++) { qm[v] = qc[v]; qc[v] = qp[v]; }
+        }
+        // keep the update above and the landing below (the scheduler otherwise sinks the register-only arithmetic
+        // under barrier (B) and waits for plane i+2 right after (A), i.e. before its latency is hidden)
+#pragma unroll
+        for (int v = 0; v < NQ; v++) asm volatile("" : "+v"(out[v]));        // the results exist HERE (no sinking below the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) land(i + 2);                                     // slot (i+2)%3 held plane i-1: its rows left LDS before (A)
+        __syncthreads();                                           // (B) every stencil read of plane i is done
+        if (cell_ok) {                                             // the evolved variables of (i, j, k) take their new values in place
+            double* ob = ring + (i % 3) * plane + x * V;
+#pragma unroll
+            for (int v = 0; v < NQ; v++)
+                if (CACHE || v < m) ob[v] = out[v];
+        }
+        __syncthreads();                                           // (C) plane i's slot holds the new plane; plane i+2 is in the ring
+        // ---- stage 3: rows j in [H, P+H) of plane i -> HBM, one contiguous block, 16-byte stores where aligned
+        {
+            const double* ob = ring + (i % 3) * plane + H * orow;
+            double* dst = Qp + (long)i * plane + (long)H * orow;
+            const int n = P * orow;
+            const int head = (int)((reinterpret_cast<unsigned long long>(dst) >> 3) & 1);
+            const int npair = (n - head) >> 1;
+            v2d* d2 = reinterpret_cast<v2d*>(dst + head);
+            for (int xx = tid; xx < npair; xx += SLAB_NT) {
+                v2d t;
+                t.x = ob[head + 2 * xx];
+                t.y = ob[head + 2 * xx + 1];
+                d2[xx] = t;
+            }
+            if (tid == 0 && head) dst[0] = ob[0];
+            if (tid == 1 && ((n - head) & 1)) dst[n - 1] = ob[n - 1];
+        }
     }
 }
 
@@ -353,10 +579,17 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
         else
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
-    } else if (DIM == 3 && P * P <= 256 && (size_t)4 * S * S * V * sizeof(double) <= 64 * 1024) {
-        // plane-streaming variant: 4-plane LDS ring, one workgroup per patch
-        hipLaunchKernelGGL((fv_rusanov_slab_kernel<PDE, MODE>), dim3((unsigned)n_patches), dim3(256), (size_t)4 * S * S * V * sizeof(double), s,
-                           Q, P, H, m, V, dt, doh, slot);
+    } else if (DIM == 3 && P * P <= 256 && S * S * V <= 2 * SLAB_NR * SLAB_NT) {
+        // plane-streaming variant: 3-plane LDS ring (+ 2 planes of per-volume scalars), one workgroup per patch
+        constexpr bool CACHE = (MODE == 1) && has_fv_cache<PDE>::value;
+        if (CACHE && m != PDE::NV) { set_error("FV Rusanov: the PDE evolves %d variables, got n_real = %d", PDE::NV, m); return -1; }
+        const size_t lds = slab_lds_bytes(S, V, CACHE);
+        auto kern = fv_rusanov_slab_kernel<PDE, MODE, CACHE>;
+        if (lds > 64 * 1024) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) { set_error("hipFuncSetAttribute(fv slab, %zu B LDS): %s", lds, hipGetErrorString(ea)); return -2; }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_patches), dim3(SLAB_NT), lds, s, Q, P, H, m, V, dt, doh, slot);
     } else if (ncell <= 4096) {
         hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
     }

@@ -91,7 +91,8 @@ def test_fv_faithful_vs_oracle_2d(exa, orc, n_patches, P, H, n_real, n_aux):
     assert np.array_equal(got, want), rel_err(got, want)
 
 
-@pytest.mark.parametrize("dim,P,H,n_aux,n_patches", [(2, 8, 1, 0, 9), (3, 4, 1, 0, 6), (3, 15, 1, 0, 2), (3, 6, 2, 3, 3)])
+@pytest.mark.parametrize("dim,P,H,n_aux,n_patches", [(2, 8, 1, 0, 9), (3, 4, 1, 0, 6), (3, 15, 1, 0, 2), (3, 6, 2, 3, 3),
+                                                      (3, 11, 2, 1, 2), (3, 16, 1, 0, 1), (3, 13, 1, 2, 3)])   # plane-streaming kernel: halo 2, aux vars, odd/even planes
 def test_fv_faithful_and_corrected_vs_oracle_euler(exa, orc, dim, P, H, n_aux, n_patches):
     S, V = P + 2 * H, 5 + n_aux
     Q = euler_patches(n_patches, dim, S, V, seed=dim * 10 + P)
@@ -115,6 +116,26 @@ def test_fv_device_resident_and_empty(exa, orc):
     assert np.array_equal(Qd.cpu().numpy(), want)
     k0 = exa.FVRusanovKernel(2, 4, 1, 5, 5, 0, exa.PDE_EULER_REF2D, exa.FV_FAITHFUL)
     k0.time_step(np.zeros((0, 6, 6, 10)), 0.1)
+
+
+@pytest.mark.parametrize("dim,P,H,n_aux,mode", [(2, 4, 1, 5, 0), (3, 15, 1, 0, 1), (3, 5, 1, 1, 1), (2, 20, 1, 0, 1)])
+def test_fv_masked_patches_are_skipped(exa, orc, dim, P, H, n_aux, mode):
+    """exa_fv_time_step_device_masked: patches whose slot entry is negative stay bit for bit as they were (every kernel
+    variant: staged small patches, register-resident, plane-streaming); the others equal the unmasked update."""
+    import torch
+    n = 7
+    S, V = P + 2 * H, 5 + n_aux
+    Q = euler_patches(n, dim, S, V, seed=4 + P)
+    pde = exa.PDE_EULER
+    k = exa.FVRusanovKernel(dim, P, H, 5, n_aux, n, pde, mode)
+    full = torch.as_tensor(Q).cuda()
+    k.time_step(full, 0.01, 0.1)
+    slot = torch.tensor([0, -1, 5, -1, -1, 2, 9], dtype=torch.int64, device="cuda")
+    part = torch.as_tensor(Q).cuda()
+    k.time_step(part, 0.01, 0.1, slot=slot)
+    a, b = part.cpu().numpy(), full.cpu().numpy()
+    on = slot.cpu().numpy() >= 0
+    assert np.array_equal(a[on], b[on]) and np.array_equal(a[~on], Q[~on]) and not np.array_equal(a[on], Q[on])
 
 
 def test_fv_rejects_bad_config(exa):
