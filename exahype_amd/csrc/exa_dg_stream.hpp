@@ -95,6 +95,13 @@ template <int N, class PDE, int HS, int OH> struct StageAStream {
     static constexpr int NT = (3 * GW > OH * OWNH) ? 3 * GW : OH * OWNH;
     static constexpr int SKEW_SLEEP = 32;                     // x 64 cycles x 32 slots ~ one iteration
     static constexpr size_t SLAB_D = (size_t)NV * N * G::NN;  // doubles of slab per workgroup: q[level][var][owner slot]
+    // Levels per slot whose new iterate stays in registers over the iteration boundary (the others wait in the slab).
+    // 1: 6 of 8 levels in the slab (120 KiB per workgroup, 3.84 MB per XCD: the cyclic sweep just misses the 4 MB L2 --
+    // 47 GB of L2 <-> fabric traffic per 32^3-cell launch against 2.35 GB algorithmic); 2: 4 levels (80 KiB, 2.56 MB per XCD).
+#ifndef EXA_STREAM_KEEP
+#define EXA_STREAM_KEEP 2
+#endif
+    static constexpr int KEEP = (OH == 1 && LS >= 2) ? EXA_STREAM_KEEP : 1;
     static_assert(HS == 1 || HS == 2, "HS");
     static_assert(OH == 1 || OH == 2, "OH");
 };
@@ -109,7 +116,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
     constexpr int NV = PDE::NV, NA = PDE::NAUX, DIM = 3;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL;
     constexpr int LG = SA::LG, LS = SA::LS, HR = SA::HR, LH = SA::LH, SLOTS = SA::SLOTS, QSZ = SA::QSZ, AXO = SA::AXO;
-    constexpr int NT = SA::NT, TH = SA::TH, HW = SA::HW, GW = SA::GW, OWNH = SA::OWNH;
+    constexpr int NT = SA::NT, TH = SA::TH, HW = SA::HW, GW = SA::GW, OWNH = SA::OWNH, KEEP = SA::KEEP;
     extern __shared__ __attribute__((aligned(16))) double lds[];
 
     const int tid = threadIdx.x;
@@ -157,6 +164,11 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
         const long cell = box.cell(b);
         double acc[LH][NV];                                      // time-update accumulators, then the final iterate
         double nxt[SLOTS][NV];                                   // what the next load phase needs, fetched a step ahead
+        double kept[KEEP > 1 ? SLOTS : 1][NV];                   // KEEP == 2: the second level of each slot (never in the slab)
+#pragma unroll
+        for (int si = 0; si < (KEEP > 1 ? SLOTS : 1); si++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) kept[si][v] = 0.0;
 #pragma unroll
         for (int k = 0; k < LH; k++)
 #pragma unroll
@@ -195,6 +207,10 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         for (int si = 0; si < SLOTS; si++) {
                             const int ls = OH == 2 ? opaque_s(o_h) : si;
                             const int ln = ls * LS + g + 1;
+                            if (KEEP > 1 && g == 0) {                            // level 1 of the slot: still in registers
+#pragma unroll
+                                for (int v = 0; v < NV; v++) nxt[si][v] = kept[KEEP > 1 ? si : 0][v];
+                            } else
                             if (ln < N EXA_ABL_COND_SLAB) {
                                 const double* row = qs + (size_t)ln * NV * NN;   // uniform base + lane offset: saddr loads
 #pragma unroll
@@ -396,7 +412,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 for (int k = 0; k < LH; k++) {
 #pragma unroll
                     for (int v = 0; v < NV; v++) acc[k][v] = nxt[0][v] - dt * acc[k][v];
-                    const bool first = OH == 2 ? k == 0 : (k == 0 || k == LS);
+                    const bool first = OH == 2 ? k == 0 : (k % LS < KEEP);         // stays in registers (nxt / kept)
                     if (!first && keep EXA_ABL_COND_SLAB && (LH * OH == N || k + 1 < LH || lp0 + k < N)) {
                         double* row = qs + (size_t)(lp0 + k) * NV * NN;          // uniform base + lane offset: saddr stores
 #pragma unroll
@@ -407,6 +423,12 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 for (int si = 0; si < SLOTS; si++)
 #pragma unroll
                     for (int v = 0; v < NV; v++) nxt[si][v] = acc[OH == 2 ? 0 : si * LS][v];
+                if constexpr (KEEP > 1) {
+#pragma unroll
+                    for (int si = 0; si < SLOTS; si++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) kept[si][v] = (si * LS + 1 < N) ? acc[si * LS + 1 < LH ? si * LS + 1 : 0][v] : 0.0;
+                }
             }
             EXA_STAMP(8);
         }
