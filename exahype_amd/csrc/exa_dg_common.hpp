@@ -24,6 +24,7 @@ template <int N> struct DgOps {
     //   DEO[h][i] = D[i][h] (the middle node's flux enters s_i - s_{N-1-i} with 2 D[i][h])
     double DEO[(N / 2) * N + N / 2 + 1];
     double Kxi[N * N];  // Kxi[i][j] = w_j D[j][i]
+    double KEO[(N / 2) * N + N / 2 + 1];   // even-odd form of Kxi (centro-antisymmetric like D: w is symmetric), same packing as DEO
     double T[N * N];    // T[l'][l]  = iK1[l'][l] * w_l   (time update; uses iK1*F0 = 1)
     double Tsum[N];     // sum_l T[l'][l]                  (iteration 0: the iterate is constant in time)
     double phiL[N];

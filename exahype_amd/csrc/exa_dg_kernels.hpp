@@ -153,6 +153,35 @@ __device__ unsigned long long g_exa_stamps[48];
 #define EXA_FMA(acc, a, b) acc += (a) * (b)
 #endif
 
+// s = M F for a centro-antisymmetric N x N matrix M given in its even-odd packing E (DgOps::DEO / KEO): half the FMAs.
+template <int N> __device__ inline void eo_apply(const double* E, const double (&F)[N], double (&s)[N]) {
+    constexpr int H = N / 2;
+    double P[H > 0 ? H : 1], M[H > 0 ? H : 1];
+#pragma unroll
+    for (int i = 0; i < H; i++) P[i] = M[i] = 0.0;
+    double mid = 0.0;
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const double e = F[j] + F[N - 1 - j], o = F[j] - F[N - 1 - j];
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            P[i] += E[j * N + i] * e;
+            M[i] += E[j * N + H + i] * o;
+        }
+        if constexpr (N % 2 == 1) mid += E[j * N + 2 * H] * o;
+    }
+    if constexpr (N % 2 == 1) {
+#pragma unroll
+        for (int i = 0; i < H; i++) P[i] += E[H * N + i] * F[H];
+        s[H] = mid;
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        s[i] = M[i] + P[i];
+        s[N - 1 - i] = M[i] - P[i];
+    }
+}
+
 template <int DIM, int N, class PDE, int CPB> struct StageA {
     using G = Geo<DIM, N>;
     // operator image in HBM: DgOps<N> | lane -> pencil tables (DIM * GW ints) | DgStepOps<N>
@@ -193,7 +222,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL, NTS = G::NTS;
     constexpr int ASZ = SA::ASZ, CS = SA::CS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ long cell_ids[2][CPB];                            // this block's cells | the next block's (ping-pong)
+    // rows 0, 1: this block's cells | the next block's (ping-pong); rows 2..7: box coordinates of the lane's slot and their step
+    // (one static array of 64 * CPB bytes: the dynamic LDS base behind it stays 16-byte aligned for the 16-byte accesses)
+    __shared__ long cell_ids[8][CPB];
 
     const int tid = threadIdx.x;
     EXA_STAMP_INIT();
@@ -228,7 +259,22 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     const long nblocks = (box.nbox + CPB - 1) / CPB;
     long blk = blockIdx.x;
     int par = 0;
-    if (tid < CPB) cell_ids[0][tid] = box.cell(blk * CPB + tid);
+    // Box slot -> cell id, kept incrementally by the CPB lanes that own a slot: the slot advances by gridDim.x * CPB per
+    // block, i.e. by a fixed (sx, sy, sz) in box coordinates with carries -- no 64-bit divisions on the path of wave 0
+    // between two cells (box.cell() costs four of them: ~2 K cycles in front of a workgroup barrier).
+    // (the state lives in LDS, not in registers: the kernel sits at its VGPR cap and anything live across the cell loop is spilled)
+    if (tid < CPB) {
+        long b = blk * CPB + tid;
+        const long cz = b % box.nb[2];
+        const long b1 = b / box.nb[2];
+        const long cy = b1 % box.nb[1], cx = b1 / box.nb[1];
+        long g = (long)gridDim.x * CPB;
+        const long sz = g % box.nb[2];
+        g /= box.nb[2];
+        cell_ids[2][tid] = cx; cell_ids[3][tid] = cy; cell_ids[4][tid] = cz;
+        cell_ids[5][tid] = g / box.nb[1]; cell_ids[6][tid] = g % box.nb[1]; cell_ids[7][tid] = sz;
+        cell_ids[0][tid] = b < box.nbox ? ((box.lo[0] + cx) * box.nc[1] + box.lo[1] + cy) * box.nc[2] + box.lo[2] + cz : -1;
+    }
     __syncthreads();                                             // cell ids visible
     double ur[NV];                                               // u of node (tc, tn) (every group reads it: 40 contiguous bytes)
     {
@@ -239,8 +285,17 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     for (; blk < nblocks; blk += gridDim.x, par ^= 1) {
     const long* cell_id = cell_ids[par];
     {
-        const long nblk = blk + gridDim.x;
-        if (tid < CPB) cell_ids[par ^ 1][tid] = nblk < nblocks ? box.cell(nblk * CPB + tid) : -1;
+        if (tid < CPB) {                                         // the next block's slot of this lane
+            long cx = cell_ids[2][tid], cy = cell_ids[3][tid], cz = cell_ids[4][tid];
+            cz += cell_ids[7][tid];
+            if (cz >= box.nb[2]) { cz -= box.nb[2]; cy += 1; }
+            cy += cell_ids[6][tid];
+            if (cy >= box.nb[1]) { cy -= box.nb[1]; cx += 1; }
+            cx += cell_ids[5][tid];
+            cell_ids[2][tid] = cx; cell_ids[3][tid] = cy; cell_ids[4][tid] = cz;
+            // (cx >= nb[0] <=> the slot is past the end of the box)
+            cell_ids[par ^ 1][tid] = cx < box.nb[0] ? ((box.lo[0] + cx) * box.nc[1] + box.lo[1] + cy) * box.nc[2] + box.lo[2] + cz : -1;
+        }
 #ifdef EXA_A_T_OLD
         if (t_task && n_it > 0) {
 #pragma unroll
@@ -465,7 +520,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             Syz0[vv] = x;
                         }
                     }
+                    EXA_STAMP(10);
                     __syncthreads();                                 // (2) S_x is in Q
+                    EXA_STAMP(11);
                     if (t_node && CNT > 0) {
                         double Ts[N];
                         sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
@@ -497,7 +554,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                                 for (int l = 0; l < N; l++) S[vv][l] += Sz[vv][l];
                         }
                     }
+                    EXA_STAMP(10);
                     __syncthreads();                                 // (2) S_x is in Q
+                    EXA_STAMP(11);
                     if (t_node && CNT > 0) {
                         double Sx[CNT > 0 ? CNT : 1][N];
 #pragma unroll
@@ -608,99 +667,113 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     }
 
     // ---- time averages (A.3) per node, one direction per group (all waves busy; q is re-read by each group):
-    //      Fbar_d -> A slab 1+d; group 0 also qbar -> A slab 0 and u -> B slab 0 (S_y, S_z are dead)
+    //      Fbar_d -> A slab 1+d; group 0 also qbar -> A slab 0 and u -> B slab 0 (S_y, S_z are dead).
+    //      One straight-line copy per group: the weights in one scalar batch, every LDS load of the node first.
     {
         const int c = bt / NN, n = bt - c * NN;
         const int off = c * CS + G::node_off(n);
-        if (bt < TD) {
-            static_for<0, DIM>([&](auto dc) {
-                constexpr int D = decltype(dc)::value;
-                if (grp == D) {
-                    const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
-                    double qb[NV], Fb[NV];
+        static_for<0, DIM>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
+            if (grp == D && bt < TD) {
+                double qb[NV], Fb[NV];
+                if (n_it > 0) {
+                    double wm[N];
+                    sload<N>(ops_here<N>(ops_raw)->w, wm);
+                    double q[NV], qn[NV];                                // level l in use, level l + 1 in flight
+#pragma unroll
+                    for (int v = 0; v < NV; v++) qn[v] = EXA_LD(off + (v * NTS + 0) * SL);
 #pragma unroll
                     for (int v = 0; v < NV; v++) qb[v] = Fb[v] = 0.0;
-                    if (n_it > 0) {
 #pragma unroll
-                        for (int l = 0; l < N; l++) {
-                            double q[NV], a[NA], F[NV];
+                    for (int l = 0; l < N; l++) {
+                        double a[NA], F[NV];
 #pragma unroll
-                            for (int v = 0; v < NV; v++) q[v] = EXA_LD(off + (v * NTS + l) * SL);
-                            PDE::aux_fast(q, a);
-                            if constexpr (D == 0) {
+                        for (int v = 0; v < NV; v++) q[v] = qn[v];
+                        if (l + 1 < N) {
 #pragma unroll
-                                for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[v];
-                            }
-                            PDE::template flux<D>(q, a, F);
-#pragma unroll
-                            for (int v = 0; v < NV; v++) Fb[v] += wm[l] * F[v];
+                            for (int v = 0; v < NV; v++) qn[v] = EXA_LD(off + (v * NTS + l + 1) * SL);
                         }
-                    } else {
-                        double a[NA];
-                        PDE::aux_fast(ur, a);
-#pragma unroll
-                        for (int v = 0; v < NV; v++) qb[v] = ur[v];
-                        PDE::template flux<D>(ur, a, Fb);
-                    }
-#pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        lds[off + ASZ + (v * NTS + 1 + D) * SL] = Fb[v];
+                        PDE::aux_fast(q, a);
                         if constexpr (D == 0) {
-                            lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
-                            lds[off + 2 * ASZ + (v * NTS + 0) * SL] = ur[v];   // same (cell, node) as the update role of this lane
+#pragma unroll
+                            for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[v];
                         }
+                        PDE::template flux<D>(q, a, F);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) Fb[v] += wm[l] * F[v];
+                    }
+                } else {
+                    double a[NA];
+                    PDE::aux_fast(ur, a);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) qb[v] = ur[v];
+                    PDE::template flux<D>(ur, a, Fb);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    lds[off + ASZ + (v * NTS + 1 + D) * SL] = Fb[v];
+                    if constexpr (D == 0) {
+                        lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
+                        lds[off + 2 * ASZ + (v * NTS + 0) * SL] = ur[v];   // same (cell, node) as the update role of this lane
                     }
                 }
-            });
-        }
+            }
+        });
     }
     __syncthreads();
     EXA_STAMP(7);
 
-    // ---- volume integral + face extrapolation: pencil tasks (c, d, v, t), t fastest
-    {
-        const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
-        for (int task = tid; task < CPB * DIM * NV * NF; task += NT) {
-            const int c = task / (DIM * NV * NF);
-            int r = task - c * (DIM * NV * NF);
-            const int d = r / (NV * NF);
-            r -= d * (NV * NF);
-            const int v = r / NF, t = r - v * NF;
-            const int ps = G::pstride(d);
-            const int off = c * CS + G::pbase(d, t) + v * NTS * SL;
-            double qb[N], Fb[N];
+    // ---- volume integral + face extrapolation: group d takes the pencils of direction d, tasks (c, v, t), t fastest.
+    //      The direction is a compile-time property of the copy (constant strides); Kxi in its even-odd form (it is
+    //      centro-antisymmetric like D: half the FMAs, 22 instead of 36 scalars at N = 6), all scalars of the phase in two
+    //      batches, the 2N LDS loads of the pencil first.
+    static_for<0, DIM>([&](auto dc) {
+        constexpr int D = decltype(dc)::value;
+        if (grp == D) {
+            constexpr int ps = G::pstride(D);
+            constexpr int TDV = CPB * NV * NF;
+            constexpr int NE = (N / 2) * N + N / 2 + 1;
+            double KE[NE], iwm[N];
+            sload<NE>(ops_here<N>(ops_raw)->KEO, KE);
+            sload<N>(ops_here<N>(ops_raw)->iw, iwm);
+            const double sc = dt * idx[D];
+            for (int task = bt; task < TDV; task += GW) {
+                const int c = task / (NV * NF);
+                const int r = task - c * (NV * NF);
+                const int v = r / NF, t = r - v * NF;
+                const int off = c * CS + G::pbase(D, t) + v * NTS * SL;
+                double qb[N], Fb[N], vol[N];
 #pragma unroll
-            for (int j = 0; j < N; j++) {
-                qb[j] = EXA_LD(off + ASZ + j * ps);
-                Fb[j] = EXA_LD(off + ASZ + (1 + d) * SL + j * ps);
-            }
-            const double sc = dt * idx[d];
+                for (int j = 0; j < N; j++) {
+                    qb[j] = EXA_LD(off + ASZ + j * ps);
+                    Fb[j] = EXA_LD(off + ASZ + (1 + D) * SL + j * ps);
+                }
+                eo_apply<N>(KE, Fb, vol);
 #pragma unroll
-            for (int i = 0; i < N; i++) {
-                double sv = 0.0;
+                for (int i = 0; i < N; i++) lds[off + (1 + D) * SL + i * ps] = sc * iwm[i] * vol[i];
+                double pl[N], pr[N];
+                sload<N>(ops_here<N>(ops_raw)->phiL, pl);
+                sload<N>(ops_here<N>(ops_raw)->phiR, pr);
+                double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
 #pragma unroll
-                for (int j = 0; j < N; j++) sv += o->Kxi[i * N + j] * Fb[j];
-                lds[off + (1 + d) * SL + i * ps] = sc * o->iw[i] * sv;
-            }
-            double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                qL += o->phiL[j] * qb[j];
-                qR += o->phiR[j] * qb[j];
-                FL += o->phiL[j] * Fb[j];
-                FR += o->phiR[j] * Fb[j];
-            }
-            const long cell = cell_id[c];
-            if (cell >= 0) {
-                double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
-                double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
-                tl[(0 * NV + v) * NF + t] = qL;
-                tl[(1 * NV + v) * NF + t] = FL;
-                tr[(0 * NV + v) * NF + t] = qR;
-                tr[(1 * NV + v) * NF + t] = FR;
+                for (int j = 0; j < N; j++) {
+                    qL += pl[j] * qb[j];
+                    qR += pr[j] * qb[j];
+                    FL += pl[j] * Fb[j];
+                    FR += pr[j] * Fb[j];
+                }
+                const long cell = cell_id[c];
+                if (cell >= 0) {
+                    double* tl = trace + (((long)D * 2 + 0) * ncells + cell) * (2 * NV * NF);
+                    double* tr = trace + (((long)D * 2 + 1) * ncells + cell) * (2 * NV * NF);
+                    tl[(0 * NV + v) * NF + t] = qL;
+                    tl[(1 * NV + v) * NF + t] = FL;
+                    tr[(0 * NV + v) * NF + t] = qR;
+                    tr[(1 * NV + v) * NF + t] = FR;
+                }
             }
         }
-    }
+    });
     __syncthreads();
     EXA_STAMP(8);
 

@@ -1,4 +1,4 @@
-"""Stage-A launch time and TFLOP/s for one (N, cells) (development aid).  usage: quick_bench_stage_a.py N cells [reps]"""
+"""Stage-A launch time and TFLOP/s for one (N, cells) (development aid).  usage: quick_bench_stage_a.py N cells [reps] [n_picard]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,7 +6,8 @@ from exahype_amd import solvers as exa
 
 N, nc = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-s = exa.AderDgSolver(3, N, (nc,) * 3)
+npic = int(sys.argv[4]) if len(sys.argv) > 4 else -1
+s = exa.AderDgSolver(3, N, (nc,) * 3, n_picard=npic)
 g = torch.Generator(device='cuda'); g.manual_seed(4)
 sh = s.u.shape[:-1]
 rho = 1 + 0.2 * torch.rand(sh, generator=g, device='cuda', dtype=torch.float64)
@@ -21,4 +22,4 @@ for _ in range(reps): s.predictor_volume(dt)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / reps * 1e-3
 w = s.work()
-print(f"stage A N={N} {nc}^3 cells: {t*1e3:.2f} ms/launch  {w['flop_a']/t/1e12:.2f} TFLOP/s  finite={bool(torch.isfinite(s.u).all())}")
+print(f"stage A N={N} n_picard={npic} {nc}^3 cells: {t*1e3:.2f} ms/launch  {w['flop_a']/t/1e12:.2f} TFLOP/s  finite={bool(torch.isfinite(s.u).all())}")

@@ -12,7 +12,7 @@ int main() {
     std::vector<double> h(ndof);
     for (long i = 0; i < ndof; i++) { int v = i % 5; h[i] = v == 0 ? 1.0 + 0.1 * ((i * 7919) % 100) / 100.0 : (v == 4 ? 2.5 + 0.1 * ((i * 104729) % 100) / 100.0 : 0.1 * (((i * 31) % 100) / 100.0 - 0.5)); }
     double *u, *tr; void* ops;
-    hipMalloc(&u, ndof * 8); hipMalloc(&tr, ntr * 8); hipMalloc(&ops, sizeof(DgOps<N>) + 16 + sizeof(int) * DIM * SA::WPD * 64);
+    hipMalloc(&u, ndof * 8); hipMalloc(&tr, ntr * 8); hipMalloc(&ops, SA::IMAGE_BYTES);
     hipMemcpy(u, h.data(), ndof * 8, hipMemcpyHostToDevice);
     DgOps<N> o{};   // the values do not matter for timing shares; keep them finite and small
     for (int i = 0; i < N; i++) { o.w[i] = 1.0 / N; o.iw[i] = N; o.phiL[i] = 0.1; o.phiR[i] = 0.1; o.Tsum[i] = 0.06; for (int j = 0; j < N; j++) { o.D[i*N+j] = 0.01*(i-j); o.DT[j*N+i] = 0.01*(i-j); o.Kxi[i*N+j] = 0.01; o.T[i*N+j] = 0.01; } }
@@ -20,7 +20,11 @@ int main() {
     {   // natural task enumeration (the library builds a conflict-free one: dg_inst.hip OpsImage)
         std::vector<int> perm(DIM * SA::WPD * 64);
         for (int d = 0; d < DIM; d++) for (int k = 0; k < SA::WPD * 64; k++) perm[d * SA::WPD * 64 + k] = k < SA::TD ? k : -1;
-        hipMemcpy((char*)ops + (sizeof(DgOps<N>) + 15) / 16 * 16, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice);
+        hipMemcpy((char*)ops + SA::PERM_OFF, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice);
+        DgStepOps<N> so;
+        for (int k = 0; k < N * N; k++) so.Tdt[k] = -1e-7;
+        for (int k = 0; k < N; k++) so.Tsdt[k] = -6e-7;
+        hipMemcpy((char*)ops + SA::STEP_OFF, &so, sizeof(so), hipMemcpyHostToDevice);
     }
     auto kern = dg_stage_a_kernel<DIM, N, Euler, CPB>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SA::LDS_BYTES);
