@@ -122,14 +122,14 @@ __device__ unsigned long long g_exa_stamps[48];
 // Diagnostic ablations (never in the product build): EXA_ABL_NOFMA drops the contraction FMAs,
 // EXA_ABL_NOLDS replaces the Picard loop's LDS reads/writes by register traffic.
 #ifdef EXA_ABL_NOLDS
-#define EXA_LD2(i) make_double2(ur[0] + (double)(i), ur[1])
+#define EXA_LD2(i) make_double2(um[0] + (double)(i), um[0])
 #define EXA_ST2(i, a, b) asm volatile("" ::"v"(a), "v"(b))
 #else
 #define EXA_LD2(i) (*reinterpret_cast<const double2*>(&lds[i]))
 #define EXA_ST2(i, a, b) *reinterpret_cast<double2*>(&lds[i]) = make_double2((a), (b))
 #endif
 #ifdef EXA_ABL_NOLDS
-#define EXA_LD(i) (ur[0] + (double)(i))
+#define EXA_LD(i) (um[0] + (double)(i))
 #define EXA_ST(i, val) asm volatile("" ::"v"(val))
 #else
 // volatile: keeps the back-end from pairing two 8-byte loads into ds_read2_b64, which runs at half the LDS rate of
@@ -244,11 +244,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     const bool t_node = bt < TD;
     const int tc = bt / NN, tn = bt - tc * NN;
     const int toff = tc * CS + G::node_off(tn);
-#ifdef EXA_A_T_OLD
-    constexpr int NVA_OLD = (NV + DIM - 1) / DIM;            // variables per group
-    const bool t_task = bt < TD && grp * ((PDE::NV + DIM - 1) / DIM) < PDE::NV;
-    const int v0 = grp * NVA_OLD < NV ? grp * NVA_OLD : NV, v1 = (grp + 1) * NVA_OLD < NV ? (grp + 1) * NVA_OLD : NV;
-#endif
 
     // derivative-phase task of this lane (conflict-free enumeration built on the host: dg_inst.hip OpsImage), -1: none
     const int d_task = grp < DIM ? reinterpret_cast<const int*>(static_cast<const char*>(ops_raw) + SA::PERM_OFF)[grp * GW + bt] : -1;
@@ -276,11 +271,16 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
         cell_ids[0][tid] = b < box.nbox ? ((box.lo[0] + cx) * box.nc[1] + box.lo[1] + cy) * box.nc[2] + box.lo[2] + cz : -1;
     }
     __syncthreads();                                             // cell ids visible
-    double ur[NV];                                               // u of node (tc, tn) (every group reads it: 40 contiguous bytes)
+    // u of node (tc, tn), the variables this lane's group updates (run-time base: the group is wave-uniform).  Only these
+    // stay in registers over the cell: the kernel sits at its VGPR cap and all five of this cell plus all five of the next
+    // one (prefetch) were what got spilled to scratch -- 9 GB of stray writes per 128^3 launch.
+    const int tvb = grp * TBASE + (grp > DIM - TREM ? grp - (DIM - TREM) : 0);
+    const int tvn = TBASE + (grp >= DIM - TREM ? 1 : 0);
+    double um[NVA > 0 ? NVA : 1];
     {
         const long cell = bt < TD ? cell_ids[0][tc] : -1;
 #pragma unroll
-        for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + tn) * NV + v] : 1.0;
+        for (int vv = 0; vv < NVA; vv++) um[vv] = cell >= 0 ? u_in[(cell * NN + tn) * NV + (vv < tvn ? tvb + vv : tvb)] : 1.0;
     }
     for (; blk < nblocks; blk += gridDim.x, par ^= 1) {
     const long* cell_id = cell_ids[par];
@@ -296,43 +296,22 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             // (cx >= nb[0] <=> the slot is past the end of the box)
             cell_ids[par ^ 1][tid] = cx < box.nb[0] ? ((box.lo[0] + cx) * box.nc[1] + box.lo[1] + cy) * box.nc[2] + box.lo[2] + cz : -1;
         }
-#ifdef EXA_A_T_OLD
-        if (t_task && n_it > 0) {
-#pragma unroll
-            for (int v = 0; v < NV; v++)
-                if (v >= v0 && v < v1) lds[toff + (v * NTS + 0) * SL] = ur[v];
-        }
-#else
         if (t_node && n_it > 0) {                                // q_0 := u; level 0 only: iteration 0 reads nothing else, its update writes all
             static_for<0, DIM>([&](auto gc) {
                 constexpr int GI = decltype(gc)::value;
                 if (grp == GI) {
 #pragma unroll
-                    for (int vv = 0; vv < tcnt(GI); vv++) lds[toff + ((tv0(GI) + vv) * NTS + 0) * SL] = ur[tv0(GI) + vv];
+                    for (int vv = 0; vv < tcnt(GI); vv++) lds[toff + ((tv0(GI) + vv) * NTS + 0) * SL] = um[vv];
                 }
             });
         }
-#endif
     }
-#ifdef EXA_A_T_OLD
-    double ur_mine[NVA_OLD];
-    int v_mine[NVA_OLD];
-#pragma unroll
-    for (int vv = 0; vv < NVA_OLD; vv++) {
-        v_mine[vv] = (v0 + vv < v1) ? v0 + vv : (v1 > 0 ? v1 - 1 : 0);
-        double x = 0.0;
-#pragma unroll
-        for (int v = 0; v < NV; v++)
-            if (v == v_mine[vv]) x = ur[v];
-        ur_mine[vv] = x;
-    }
-#endif
     __syncthreads();
-    double un[NV];                                               // u of the next block's node, in flight during this block
+    double unm[NVA > 0 ? NVA : 1];                               // the same of the next block's node, in flight during this block
     {
         const long cn = bt < TD ? cell_ids[par ^ 1][tc] : -1;
 #pragma unroll
-        for (int v = 0; v < NV; v++) un[v] = cn >= 0 ? u_in[(cn * NN + tn) * NV + v] : 1.0;
+        for (int vv = 0; vv < NVA; vv++) unm[vv] = cn >= 0 ? u_in[(cn * NN + tn) * NV + (vv < tvn ? tvb + vv : tvb)] : 1.0;
     }
     EXA_STAMP(0);
 
@@ -487,7 +466,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 }
             }
         });
-#ifndef EXA_A_T_OLD
         EXA_STAMP(1);
         __syncthreads();                                             // (1) every read of Q is done; S_y (A) and S_z (B) are complete
         EXA_STAMP(2);
@@ -530,7 +508,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         for (int vv = 0; vv < CNT; vv++) {
                             const int o = toff + ((V0 + vv) * NTS + 0) * SL;
                             const double x = EXA_LD(o) + Syz0[vv];
-                            const double uv = ur[V0 + vv];
+                            const double uv = um[vv];
 #pragma unroll
                             for (int lp = 0; lp < N; lp++) EXA_ST(toff + ((V0 + vv) * NTS + lp) * SL, fma(Ts[lp], x, uv));
                         }
@@ -577,7 +555,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             sload<RN * N>(step_here<N>(step_raw)->Tdt + R0 * N, Tm);
 #pragma unroll
                             for (int vv = 0; vv < CNT; vv++) {
-                                const double uv = ur[V0 + vv];
+                                const double uv = um[vv];
 #pragma unroll
                                 for (int r = 0; r < RN; r++) {
                                     double acc = uv;
@@ -594,73 +572,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 #endif
             }
         });
-#else
-        EXA_STAMP(1);
-        __syncthreads();
-        EXA_STAMP(2);
-        {
-            if (did_x) {                                             // every read of Q is done: Q := S_x
-                constexpr int ps = G::pstride(0);
-#pragma unroll
-                for (int i = 0; i < N; i++)
-#pragma unroll
-                    for (int v = 0; v < NV; v++) EXA_ST(zoff + v * NTS * SL + i * ps, s[i][v]);
-            }
-            EXA_STAMP(10);
-            __syncthreads();
-            EXA_STAMP(11);
-        }
-        // ---- time contraction, split by variable between the two lanes of a pair
-#ifndef EXA_ABL_SKIP_T
-        if (t_task && it == 0) {
-            const EXA_AS4 double* Ts = ops_here<N>(ops_raw)->Tsum;        // row sums of T
-#pragma unroll
-            for (int vv = 0; vv < NVA_OLD; vv++) {
-                if (v0 + vv < v1) {
-                    const int o = toff + ((v0 + vv) * NTS + 0) * SL;
-                    double x = EXA_LD(o) + EXA_LD(o + ASZ);
-                    if constexpr (DIM == 3) x += EXA_LD(o + 2 * ASZ);
-                    const double uv = ur_mine[vv];
-#pragma unroll
-                    for (int lp = 0; lp < N; lp++) EXA_ST(toff + ((v0 + vv) * NTS + lp) * SL, uv - dt * Ts[lp] * x);
-                }
-            }
-        } else if (t_task) {
-            const EXA_AS4 double* Tm = ops_here<N>(ops_raw)->T;
-            // software pipeline over the variables: the loads of variable vv+1 are in flight while the
-            // FMAs of variable vv run (all-loads-then-all-FMAs cost LDS time + VALU time back to back)
-            double Sa[N], Sb[N], Sc[N];
-            auto issue = [&](int vv) {
-#pragma unroll
-                for (int l = 0; l < N; l++) {
-                    const int o = toff + (v_mine[vv] * NTS + l) * SL;
-                    Sa[l] = EXA_LD(o);
-                    Sb[l] = EXA_LD(o + ASZ);
-                    if constexpr (DIM == 3) Sc[l] = EXA_LD(o + 2 * ASZ);
-                }
-            };
-            issue(0);
-#pragma unroll
-            for (int vv = 0; vv < NVA_OLD; vv++) {
-                double S[N];
-#pragma unroll
-                for (int l = 0; l < N; l++) {
-                    S[l] = Sa[l] + Sb[l];
-                    if constexpr (DIM == 3) S[l] += Sc[l];
-                }
-                if (vv + 1 < NVA_OLD) issue(vv + 1);
-                const double uv = ur_mine[vv];
-#pragma unroll
-                for (int lp = 0; lp < N; lp++) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < N; l++) EXA_FMA(acc, Tm[lp * N + l], S[l]);
-                    EXA_ST(toff + (v_mine[vv] * NTS + lp) * SL, uv - dt * acc);
-                }
-            }
-        }
-#endif
-#endif
         EXA_STAMP(3);
         __syncthreads();                                             // (3) the new iterate is in Q
         EXA_STAMP(4);
@@ -676,6 +587,14 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             constexpr int D = decltype(dc)::value;
             if (grp == D && bt < TD) {
                 double qb[NV], Fb[NV];
+                // all variables of u at this node: for the single-stage case, and (group 0) for the B slab the final sum reads;
+                // requested first, used last (an L2 hit: the cell was read at its start)
+                double ur[NV];
+                if (D == 0 || n_it <= 0) {
+                    const long cell = cell_id[c];
+#pragma unroll
+                    for (int v = 0; v < NV; v++) ur[v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
+                }
                 if (n_it > 0) {
                     double wm[N];
                     sload<N>(ops_here<N>(ops_raw)->w, wm);
@@ -791,7 +710,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     EXA_STAMP(9);
     __syncthreads();                                             // LDS and the cell-id slot are reused by the next block
 #pragma unroll
-    for (int v = 0; v < NV; v++) ur[v] = un[v];
+    for (int vv = 0; vv < NVA; vv++) um[vv] = unm[vv];
     }
     EXA_STAMP_FLUSH();
 }

@@ -5,8 +5,9 @@
 //                               subcell layer of the face neighbours' projections (periodic in the block), edge
 //                               and corner halo entries = nearest interior value (never read by the 7-point stencil)
 //   limiter_reconstruct_kernel  FV patch interior -> DG nodes: u = (R x R x R) v
-// One workgroup per troubled cell; the tensor products run variable by variable through two LDS buffers.  These
-// touch ~5 % of the cells: written for clarity, not tuned.
+// One workgroup per troubled cell; the tensor products run variable by variable through two LDS buffers.  The kernels are
+// instantiated per order (N, N_s compile-time): with run-time extents every output element paid three integer divisions
+// (~100 instructions) for its 8 FMAs -- 7.6 ms per step for the 13 K patches of cfg 4's per-GPU shape, 8 % of the step.
 #include <cstdio>
 #include "exa_launch.hpp"
 
@@ -16,26 +17,34 @@ constexpr int LIM_MAX = 15 * 15 * 15;      // largest intermediate: Ns^3 at p = 
 
 // out[.., r, ..] = sum_c M[r0 + r][c] in[.., c, ..] along `axis` of a row-major array with extents e[0..dim)
 // (extent C along `axis` on input, nr on output)
-__device__ inline void lim_apply(const double* __restrict__ M, int ldm, int r0, int nr, int C, const double* in, double* out,
+// C: compile-time contraction length (N or N_s); the extents along the other axes take few distinct values, so the
+// divisions by `inner` / `nr` are done once per element with 32-bit unsigned arithmetic on small numbers
+template <int C>
+__device__ inline void lim_apply(const double* __restrict__ M, int ldm, int r0, int nr, const double* in, double* out,
                                  int dim, const int* e, int axis) {
-    int inner = 1, outer = 1;
+    unsigned inner = 1, outer = 1;
     for (int a = axis + 1; a < dim; a++) inner *= e[a];
     for (int a = 0; a < axis; a++) outer *= e[a];
-    const int total = outer * nr * inner;
-    for (int t = threadIdx.x; t < total; t += blockDim.x) {
-        const int in_i = t % inner, r = (t / inner) % nr, o = t / (inner * nr);
+    const unsigned total = outer * nr * inner;
+    for (unsigned t = threadIdx.x; t < total; t += blockDim.x) {
+        const unsigned q = t / inner, in_i = t - q * inner;
+        const unsigned o = q / (unsigned)nr, r = q - o * nr;
+        const double* mr = M + (r0 + r) * ldm;
+        const double* ip = in + (o * C) * inner + in_i;
         double acc = 0.0;
-        for (int c = 0; c < C; c++) acc += M[(r0 + r) * ldm + c] * in[(o * C + c) * inner + in_i];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc += mr[c] * ip[c * inner];
         out[t] = acc;
     }
 }
 
-template <int DIM>
+template <int DIM, int N>
 __global__ void __launch_bounds__(256)
-limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, const double* __restrict__ u,
+limiter_project_kernel(int, int, int nv, long nc0, long nc1, long nc2, const double* __restrict__ u,
                        const long* __restrict__ cells, double* __restrict__ patch, const double* __restrict__ P,
                        LimGhosts gh) {
     __shared__ double A[LIM_MAX], B[LIM_MAX];
+    constexpr int Ns = 2 * N - 1;
     const long cell = cells[blockIdx.x];
     if (cell < 0) return;                                          // empty slot of a capacity-sized cell list
     const int S = Ns + 2;
@@ -52,7 +61,7 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
         int e[3] = {N, N, N};
         double *src = A, *dst = B;
         for (int a = 0; a < DIM; a++) {
-            lim_apply(P, N, 0, Ns, N, src, dst, DIM, e, a);
+            lim_apply<N>(P, N, 0, Ns, src, dst, DIM, e, a);
             e[a] = Ns;
             __syncthreads();
             double* tmp = src; src = dst; dst = tmp;
@@ -106,8 +115,8 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
                 double *s2 = A, *d2 = B;
                 for (int bb = 0; bb < DIM; bb++) {
                     const int b = (a + bb) % DIM;                // normal axis first: the other passes see one layer only
-                    if (b == a) lim_apply(P, N, side ? 0 : Ns - 1, 1, N, s2, d2, DIM, e2, b);     // the adjacent layer only
-                    else lim_apply(P, N, 0, Ns, N, s2, d2, DIM, e2, b);
+                    if (b == a) lim_apply<N>(P, N, side ? 0 : Ns - 1, 1, s2, d2, DIM, e2, b);     // the adjacent layer only
+                    else lim_apply<N>(P, N, 0, Ns, s2, d2, DIM, e2, b);
                     e2[b] = (b == a) ? 1 : Ns;
                     __syncthreads();
                     double* tmp = s2; s2 = d2; d2 = tmp;
@@ -133,11 +142,12 @@ limiter_project_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, cons
 // Sharded grids: the subcell layer next to the block face (a, side) of every cell of the block's boundary layer whose
 // neighbour across the face is troubled (need[t] != 0; need == nullptr: all) -- what that neighbour's patch needs as
 // halo.  out[transverse cell][transverse subcell][var]; one workgroup per transverse cell.
-template <int DIM>
+template <int DIM, int N>
 __global__ void __launch_bounds__(256)
-limiter_face_layers_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, const double* __restrict__ u, int a, int side,
+limiter_face_layers_kernel(int, int, int nv, long nc0, long nc1, long nc2, const double* __restrict__ u, int a, int side,
                            const double* __restrict__ need, double* __restrict__ out, const double* __restrict__ P) {
     __shared__ double A[LIM_MAX], B[LIM_MAX];
+    constexpr int Ns = 2 * N - 1;
     const long tc = blockIdx.x;
     if (need && need[tc] == 0.0) return;
     const long nc[3] = {nc0, nc1, nc2};
@@ -155,8 +165,8 @@ limiter_face_layers_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, 
         double *src = A, *dst = B;
         for (int bb = 0; bb < DIM; bb++) {
             const int b = (a + bb) % DIM;                        // normal axis first
-            if (b == a) lim_apply(P, N, side ? Ns - 1 : 0, 1, N, src, dst, DIM, e, b);     // the layer at the face only
-            else lim_apply(P, N, 0, Ns, N, src, dst, DIM, e, b);
+            if (b == a) lim_apply<N>(P, N, side ? Ns - 1 : 0, 1, src, dst, DIM, e, b);     // the layer at the face only
+            else lim_apply<N>(P, N, 0, Ns, src, dst, DIM, e, b);
             e[b] = (b == a) ? 1 : Ns;
             __syncthreads();
             double* tmp = src; src = dst; dst = tmp;
@@ -166,11 +176,12 @@ limiter_face_layers_kernel(int N, int Ns, int nv, long nc0, long nc1, long nc2, 
     }
 }
 
-template <int DIM>
+template <int DIM, int N>
 __global__ void __launch_bounds__(256)
-limiter_reconstruct_kernel(int N, int Ns, int nv, const double* __restrict__ patch, const long* __restrict__ cells,
+limiter_reconstruct_kernel(int, int, int nv, const double* __restrict__ patch, const long* __restrict__ cells,
                            double* __restrict__ u, const double* __restrict__ R) {
     __shared__ double A[LIM_MAX], B[LIM_MAX];
+    constexpr int Ns = 2 * N - 1;
     const long cell = cells[blockIdx.x];
     if (cell < 0) return;                                          // empty slot
     const int S = Ns + 2;
@@ -188,7 +199,7 @@ limiter_reconstruct_kernel(int N, int Ns, int nv, const double* __restrict__ pat
         int e[3] = {Ns, Ns, Ns};
         double *src = A, *dst = B;
         for (int a = 0; a < DIM; a++) {
-            lim_apply(R, Ns, 0, N, Ns, src, dst, DIM, e, a);
+            lim_apply<Ns>(R, Ns, 0, N, src, dst, DIM, e, a);
             e[a] = N;
             __syncthreads();
             double* tmp = src; src = dst; dst = tmp;
@@ -198,13 +209,23 @@ limiter_reconstruct_kernel(int N, int Ns, int nv, const double* __restrict__ pat
     }
 }
 
+#define EXA_LIM_CASES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+
 int limiter_project(int dim, int N, int Ns, int nv, const long* nc, const double* u, const long* cells, long n, double* patch,
                     const double* Pdev, const LimGhosts* ghosts, hipStream_t s) {
     if (n <= 0) return 0;
     LimGhosts gh{};
     if (ghosts) gh = *ghosts;
-    if (dim == 2) hipLaunchKernelGGL((limiter_project_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, cells, patch, Pdev, gh);
-    else hipLaunchKernelGGL((limiter_project_kernel<3>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, cells, patch, Pdev, gh);
+    switch (N) {
+#define X(NN_)                                                                                                                         \
+    case NN_:                                                                                                                          \
+        if (dim == 2) hipLaunchKernelGGL((limiter_project_kernel<2, NN_>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, cells, patch, Pdev, gh); \
+        else hipLaunchKernelGGL((limiter_project_kernel<3, NN_>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, cells, patch, Pdev, gh);      \
+        break;
+        EXA_LIM_CASES(X)
+#undef X
+    default: set_error("limiter: N = %d is not built", N); return -1;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("limiter_project launch: %s", hipGetErrorString(e)); return -2; }
     return 0;
@@ -216,8 +237,16 @@ int limiter_face_layers(int dim, int N, int Ns, int nv, const long* nc, const do
     for (int b = 0; b < dim; b++)
         if (b != a) nt *= nc[b];
     if (nt <= 0) return 0;
-    if (dim == 2) hipLaunchKernelGGL((limiter_face_layers_kernel<2>), dim3((unsigned)nt), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, a, side, need, out, Pdev);
-    else hipLaunchKernelGGL((limiter_face_layers_kernel<3>), dim3((unsigned)nt), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, a, side, need, out, Pdev);
+    switch (N) {
+#define X(NN_)                                                                                                                         \
+    case NN_:                                                                                                                          \
+        if (dim == 2) hipLaunchKernelGGL((limiter_face_layers_kernel<2, NN_>), dim3((unsigned)nt), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], 1L, u, a, side, need, out, Pdev); \
+        else hipLaunchKernelGGL((limiter_face_layers_kernel<3, NN_>), dim3((unsigned)nt), dim3(256), 0, s, N, Ns, nv, nc[0], nc[1], nc[2], u, a, side, need, out, Pdev);      \
+        break;
+        EXA_LIM_CASES(X)
+#undef X
+    default: set_error("limiter: N = %d is not built", N); return -1;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("limiter_face_layers launch: %s", hipGetErrorString(e)); return -2; }
     return 0;
@@ -226,8 +255,16 @@ int limiter_face_layers(int dim, int N, int Ns, int nv, const long* nc, const do
 int limiter_reconstruct(int dim, int N, int Ns, int nv, const double* patch, const long* cells, long n, double* u,
                         const double* Rdev, hipStream_t s) {
     if (n <= 0) return 0;
-    if (dim == 2) hipLaunchKernelGGL((limiter_reconstruct_kernel<2>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, patch, cells, u, Rdev);
-    else hipLaunchKernelGGL((limiter_reconstruct_kernel<3>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, patch, cells, u, Rdev);
+    switch (N) {
+#define X(NN_)                                                                                                                         \
+    case NN_:                                                                                                                          \
+        if (dim == 2) hipLaunchKernelGGL((limiter_reconstruct_kernel<2, NN_>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, patch, cells, u, Rdev); \
+        else hipLaunchKernelGGL((limiter_reconstruct_kernel<3, NN_>), dim3((unsigned)n), dim3(256), 0, s, N, Ns, nv, patch, cells, u, Rdev);      \
+        break;
+        EXA_LIM_CASES(X)
+#undef X
+    default: set_error("limiter: N = %d is not built", N); return -1;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("limiter_reconstruct launch: %s", hipGetErrorString(e)); return -2; }
     return 0;
