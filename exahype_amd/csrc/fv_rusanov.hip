@@ -47,7 +47,12 @@ template <int TP, int TH, int TM, int TV> struct FvShape {
 };
 using FvRuntimeShape = FvShape<0, 0, 0, 0>;
 
-template <int DIM, class PDE, int MODE, int CPT, int NT, bool STAGE, class SHAPE = FvRuntimeShape>
+// PERSIST (staged small patches only): the grid is as many workgroups as the chip holds; a workgroup walks over the blocks
+// of `ppb` patches and requests the NEXT block into registers (16-byte loads at clamped indices, no load under a lane
+// condition) before it updates the current one from LDS -- the 46 KB read of a block overlaps the stencil and the
+// write-back of its predecessor instead of standing alone in front of a barrier.
+constexpr int FV_HR = 16;          // double2 per thread that hold a block in flight (<= 64 KiB per block at 256 threads)
+template <int DIM, class PDE, int MODE, int CPT, int NT, bool STAGE, class SHAPE = FvRuntimeShape, bool PERSIST = false>
 __global__ void __launch_bounds__(NT)
 fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt, double dt, double dt_over_h, long n_patches,
                   int ppb, const long* __restrict__ slot) {
@@ -60,18 +65,50 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
     const long vol = (DIM == 3) ? (long)S * S * S : (long)S * S;
     const int ncell = (DIM == 3) ? P * P * P : P * P;
     const int pl = (CPT == 1) ? (int)threadIdx.x / ncell : 0;            // patch slot of this thread
-    const long patch = (long)blockIdx.x * ppb + pl;
+    static_assert(!PERSIST || (STAGE && CPT == 1), "the persistent form is the staged small-patch kernel");
+    const long nblk = (n_patches + ppb - 1) / ppb;
+    const long blk_step = PERSIST ? (long)gridDim.x : nblk;      // not persistent: exactly one pass, block = blockIdx.x
+    // registers that hold a block in flight: exact for a compile-time shape (the reference's: 12), FV_HR otherwise
+    constexpr int SPOW = SHAPE::P ? (DIM == 3 ? (SHAPE::P + 2 * SHAPE::H) * (SHAPE::P + 2 * SHAPE::H) * (SHAPE::P + 2 * SHAPE::H) : (SHAPE::P + 2 * SHAPE::H) * (SHAPE::P + 2 * SHAPE::H)) : 0;
+    constexpr int PPOW = SHAPE::P ? (DIM == 3 ? SHAPE::P * SHAPE::P * SHAPE::P : SHAPE::P * SHAPE::P) : 1;
+    constexpr int HRS = !PERSIST ? 1 : (SHAPE::P ? ((NT / PPOW) * SPOW * SHAPE::V / 2 + NT - 1) / NT : FV_HR);
+    v2d hold[HRS];
+    auto request = [&](long blk) {                                // block blk -> registers (PERSIST: Q 16-byte aligned, even block size)
+        const long first = blk * ppb;
+        const long npatch = (n_patches - first < ppb) ? n_patches - first : ppb;
+        const int npair = (int)(npatch * vol * V / 2);
+        const v2d* s2 = reinterpret_cast<const v2d*>(Q + first * vol * V);
+#pragma unroll
+        for (int r = 0; r < HRS; r++) {
+            const int xx = (int)threadIdx.x + r * NT;
+            hold[r] = s2[xx < npair ? xx : npair - 1];
+        }
+    };
+    if constexpr (PERSIST) request(blockIdx.x);
+    for (long blk = blockIdx.x; blk < nblk; blk += blk_step) {
+    const long patch = blk * ppb + pl;
     // slot (optional): one entry per patch, < 0 = this patch is not in use (exa_fv_time_step_device_masked: the
     // number of patches in use is known on the device only, the launch covers the array's capacity)
     const bool live = pl < ppb && patch < n_patches && (!slot || slot[patch] >= 0);
     double* Qg = Q + (live ? patch : 0) * vol * V;              // this thread's patch in HBM (writes)
     const double* Qp = Qg;                                       // ... and where the stencil reads it
     if constexpr (STAGE) {
-        const long first = (long)blockIdx.x * ppb;
+        const long first = blk * ppb;
         const long npatch = (n_patches - first < ppb) ? n_patches - first : ppb;
         const long total = npatch * vol * V;                     // doubles in this workgroup's block
         const double* src = Q + first * vol * V;
         const bool al16 = ((reinterpret_cast<unsigned long long>(src) & 15) == 0);
+        if constexpr (PERSIST) {
+            const int npair = (int)(total / 2);
+            v2d* d2 = reinterpret_cast<v2d*>(fv_lds);
+#pragma unroll
+            for (int r = 0; r < HRS; r++) {
+                const int xx = (int)threadIdx.x + r * NT;
+                if (xx < npair) d2[xx] = hold[r];
+            }
+            __syncthreads();
+            if (blk + blk_step < nblk) request(blk + blk_step);  // in flight during the update and the write-back below
+        } else
         if (al16) {
             const double2* s2 = reinterpret_cast<const double2*>(src);
             double2* d2 = reinterpret_cast<double2*>(fv_lds);
@@ -80,7 +117,7 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
         } else {
             for (long i = threadIdx.x; i < total; i += NT) fv_lds[i] = src[i];
         }
-        __syncthreads();
+        if constexpr (!PERSIST) __syncthreads();
         Qp = fv_lds + (long)(live ? pl : 0) * vol * V;
     }
     long st[3];
@@ -197,11 +234,14 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
                 if (v < m) Ql[cidx[k] * V + v] = nv[k][v];
         }
         __syncthreads();
-        const long first = (long)blockIdx.x * ppb;
+        const long first = blk * ppb;
         const long npatch = (n_patches - first < ppb) ? n_patches - first : ppb;
         const int rows_pp = (DIM == 3) ? P * P : P;                  // interior rows per patch
         const int r2 = P * V / 2;                                    // double2 per row
         double* dst = Q + first * vol * V;
+        // (tried in r2: rows j in [H, P+H) with ALL k as one contiguous block per patch, the k-halo volumes rewriting their old
+        // values -- no partial lines but +50 % bytes written at P = 4: 1.07 ms against 1.00 ms; the kernel moves its ACTUAL
+        // 4.5 GB at 4.5 TB/s either way)
         for (long e = threadIdx.x; e < npatch * rows_pp * r2; e += NT) {
             const long row = e / r2;
             const int x = (int)(e - row * r2);
@@ -219,6 +259,8 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             for (int v = 0; v < MAXV; v++)
                 if (v < m) Qg[cidx[k] * V + v] = nv[k][v];
         }
+    }
+    if constexpr (PERSIST) __syncthreads();                      // the LDS copy is free for the next block
     }
 }
 
@@ -567,9 +609,25 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
         const int ppb = (int)(256 / ncell);
         const dim3 grid((unsigned)((n_patches + ppb - 1) / ppb));
         const size_t lds = (size_t)ppb * pvol * V * sizeof(double);
-        if (DIM == 2 && P == 4 && H == 1 && m == 5 && V == 10)      // the reference's configuration (Batched_stateless.py:9)
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
-        else if (lds <= 64 * 1024)       // staged: up to two workgroups per CU keep HBM requests in flight
+        // persistent form (next block requested into registers during the update of this one): Q 16-byte aligned, an even
+        // number of doubles per block, a grid that fills the chip once
+        const bool persist = lds <= 64 * 1024 && ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (((long)ppb * pvol * V) % 2 == 0) &&
+                             n_patches >= (long)ppb * 2048;
+        auto persist_grid = [&](const void* kern) -> unsigned {
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+                return 0;
+            const long g = (long)per_cu * cus, nb = (n_patches + ppb - 1) / ppb;
+            return (unsigned)(g < nb ? g : nb);
+        };
+        if (DIM == 2 && P == 4 && H == 1 && m == 5 && V == 10) {    // the reference's configuration (Batched_stateless.py:9)
+            auto kp = fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>, true>;
+            const unsigned pg = persist ? persist_grid(reinterpret_cast<const void*>(kp)) : 0;
+            if (pg > 0) hipLaunchKernelGGL(kp, dim3(pg), dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
+            else hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
+        } else if (lds <= 64 * 1024)     // staged: several workgroups per CU keep HBM requests in flight (the persistent form
+                                         // with its 64 holding VGPRs lost there: 2-D P = 16 0.55 -> 0.67 ms)
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
         else
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, false>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);

@@ -351,6 +351,50 @@ def test_dg_full_size_conservation_128cubed(exa):
     assert np.max(np.abs(m1 - m0) / np.abs(m0)) < 1e-12, (m0, m1)
 
 
+def test_fv_full_size_replicated_golden_patch(exa, golden_dir):
+    """SURVEY.md 8(d) FV-parity row at its full batch size (2^20 patches of the reference's configuration): every patch is
+    the reference protocol's sin patch, so every patch must come out as the reference's golden vector -- bit for bit, the
+    same in all 2^20 patches (a checksum of checksums: no patch slot, workgroup or XCD treats its data differently)."""
+    import torch
+    g = json.load(open(os.path.join(golden_dir, "fv_ref2d_sin.json")))
+    n = 1 << 20
+    one = torch.as_tensor(np.sin(3.141 * np.arange(360) / 360)).cuda()
+    Q = one.repeat(n).reshape(n, 360)
+    k = exa.FVRusanovKernel(2, 4, 1, 5, 5, n, exa.PDE_EULER_REF2D, exa.FV_FAITHFUL)
+    k.time_step(Q.reshape(-1), 1.0)
+    torch.cuda.synchronize()
+    assert bool((Q == Q[0]).all())                                           # all patches identical ...
+    first = Q[0].cpu().numpy()
+    idx = np.array(g["valid_modified_idx"])
+    assert np.array_equal(first[idx], np.array(g["valid_modified_val"]))     # ... and equal to the reference's output
+    pidx = np.array(g["passthrough_idx"])
+    assert np.array_equal(first[pidx], one.cpu().numpy()[pidx])
+
+
+def test_dg_full_size_conservation_cfg1_512sq(exa):
+    """configs[1] (2-D Euler p=3, 512 x 512 cells, single stage, fused launch): three steps conserve all variables to round-off."""
+    import torch
+    N, nc = 4, (512, 512)
+    s = exa.AderDgSolver(2, N, nc, n_picard=0, fused_single_stage=True)
+    assert s._fused
+    w = torch.as_tensor(s.operators()["w"], device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    sh = s.u.shape[:-1]
+    for v, (base, amp) in enumerate(((1.0, 0.2), (0.5, 0.1), (-0.3, 0.1), (0.0, 0.0), (3.0, 0.2))):
+        s.u[..., v] = base + amp * torch.rand(sh, generator=g, device="cuda", dtype=torch.float64)
+
+    def mass():
+        return np.array([float(torch.einsum("abij,i,j->", s.u[..., v], w, w)) for v in range(5)])
+    m0 = mass()
+    for _ in range(3):
+        s.step(1e-6)
+    torch.cuda.synchronize()
+    m1 = mass()
+    assert bool(torch.isfinite(s.u).all())
+    ok = np.abs(m0) > 0
+    assert np.max(np.abs(m1 - m0)[ok] / np.abs(m0)[ok]) < 1e-12 and np.all(np.abs(m1[~ok]) < 1e-9), (m0, m1)
+
+
 @pytest.mark.parametrize("N,nc", [(4, (5, 3)), (2, (4, 4)), (8, (2, 3)), (6, (7, 4)), (3, (1, 9))])
 def test_dg_fused_single_stage_step_vs_oracle(exa, orc, N, nc):
     """Opt-in fused single-stage 2-D step (exa_dg_step_fused: traces stay on chip) == oracle; partial tiles, tiny grids."""
