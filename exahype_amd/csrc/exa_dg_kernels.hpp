@@ -182,6 +182,69 @@ template <int N> __device__ inline void eo_apply(const double* E, const double (
     }
 }
 
+// Derivative sums of one pencil whose N nodes (NV variables each) are in registers:  s[i][v] = sum_j D[i][j] * (1/dx_D) f_D(q_j)[v],
+// even-odd form of the centro-antisymmetric D (E = DgOps::DEO through a laundered constant-address-space pointer).
+template <int D, int N, class PDE>
+__device__ inline void pencil_sums(const double (&qw)[N][PDE::NV], const EXA_AS4 double* Em, double idx_d, double (&s)[N][PDE::NV]) {
+    constexpr int NV = PDE::NV, NA = PDE::NAUX, H = N / 2;
+    double P[H > 0 ? H : 1][NV], M[H > 0 ? H : 1][NV], mid[NV];
+#pragma unroll
+    for (int i = 0; i < H; i++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) P[i][v] = M[i][v] = 0.0;
+#pragma unroll
+    for (int v = 0; v < NV; v++) mid[v] = 0.0;
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int jm = N - 1 - j;
+        double aa[NA], ab[NA], Fa[NV], Fb[NV];
+        PDE::aux_fast(qw[j], aa);
+        PDE::template flux_scaled<D>(qw[j], aa, idx_d, Fa);
+        PDE::aux_fast(qw[jm], ab);
+        PDE::template flux_scaled<D>(qw[jm], ab, idx_d, Fb);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
+            Fa[v] = e;
+            Fb[v] = o;
+        }
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const double ea = Em[j * N + i], eb = Em[j * N + H + i];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                EXA_FMA(P[i][v], ea, Fa[v]);
+                EXA_FMA(M[i][v], eb, Fb[v]);
+            }
+        }
+        if constexpr (N % 2 == 1) {
+            const double em = Em[j * N + 2 * H];
+#pragma unroll
+            for (int v = 0; v < NV; v++) EXA_FMA(mid[v], em, Fb[v]);
+        }
+    }
+    if constexpr (N % 2 == 1) {
+        double aa[NA], Fa[NV];
+        PDE::aux_fast(qw[H], aa);
+        PDE::template flux_scaled<D>(qw[H], aa, idx_d, Fa);
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const double ec = Em[H * N + i];
+#pragma unroll
+            for (int v = 0; v < NV; v++) EXA_FMA(P[i][v], ec, Fa[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) s[H][v] = mid[v];
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            s[i][v] = M[i][v] + P[i][v];
+            s[N - 1 - i][v] = M[i][v] - P[i][v];
+        }
+}
+
 template <int DIM, int N, class PDE, int CPB> struct StageA {
     using G = Geo<DIM, N>;
     // operator image in HBM: DgOps<N> | lane -> pencil tables (DIM * GW ints) | DgStepOps<N>
@@ -195,6 +258,20 @@ template <int DIM, int N, class PDE, int CPB> struct StageA {
     static constexpr int NT = DIM * WPD * 64;                // threads per workgroup
     static constexpr size_t STEP_OFF = (PERM_OFF + sizeof(int) * DIM * WPD * 64 + 15) / 16 * 16;
     static constexpr size_t IMAGE_BYTES = STEP_OFF + sizeof(DgStepOps<N>);
+    // which form of the Picard loop (see the kernel): measured per order on 3-D Euler, 64^3 cells
+    //   0 "late":  x group stores S_x over Q after barrier (1), barrier (2), time update
+    //   1 "early": every pencil loaded, barrier (R), sums stored at once, barrier (1), time update
+    //   2 "flag":  as 0, but the x group waits for a count of the y / z waves whose pencil loads are done instead of for
+    //              barrier (1), and stores S_x beside their arithmetic; barrier (2) is gone
+#if defined(EXA_A_EARLY_STORE)
+    static constexpr int MODE = 1;
+#elif defined(EXA_A_LATE_STORE)
+    static constexpr int MODE = 0;
+#elif defined(EXA_A_FLAG)
+    static constexpr int MODE = 2;
+#else
+    static constexpr int MODE = (DIM == 3 && (N == 5 || N == 3)) ? 1 : 0;
+#endif
 };
 
 // Cell image in LDS: three q-sized arrays Q | A | B, each SoA [var][time slab][node].
@@ -224,7 +301,8 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // rows 0, 1: this block's cells | the next block's (ping-pong); rows 2..7: box coordinates of the lane's slot and their step
     // (one static array of 64 * CPB bytes: the dynamic LDS base behind it stays 16-byte aligned for the 16-byte accesses)
-    __shared__ long cell_ids[8][CPB];
+    __shared__ long cell_ids[SA::MODE == 2 ? 10 : 8][CPB];     // (MODE 2: row 8 holds the reader count, as an int)
+    [[maybe_unused]] int* q_readers = reinterpret_cast<int*>(&cell_ids[SA::MODE == 2 ? 8 : 0][0]);
 
     const int tid = threadIdx.x;
     EXA_STAMP_INIT();
@@ -285,6 +363,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     for (; blk < nblocks; blk += gridDim.x, par ^= 1) {
     const long* cell_id = cell_ids[par];
     {
+        if constexpr (SA::MODE == 2) {
+            if (tid == 0) *q_readers = 0;
+        }
         if (tid < CPB) {                                         // the next block's slot of this lane
             long cx = cell_ids[2][tid], cy = cell_ids[3][tid], cz = cell_ids[4][tid];
             cz += cell_ids[7][tid];
@@ -317,6 +398,69 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 
     // ---- Picard iterations (A.2):  q <- u - dt * T * sum_d (1/dx_d) D_d f_d(q)
     for (int it = 0; it < n_it; it++) {
+    constexpr int W0 = (CPB * NF + 63) / 64;                     // iteration 0: the l = 0 pencils, packed on W0 waves per direction
+    const int wave = tid >> 6;
+    if constexpr (SA::MODE == 1) {
+    // Form with an early "reads done" barrier: every lane loads its whole pencil, barrier (R), then computes and stores its
+    // sums at once -- x over Q (nobody reads Q any more), y -> A, z -> B.  The serial phase of the other form (x group stores
+    // after barrier (1) while the others wait, then barrier (2)) is gone; its price is that no flux is evaluated before the
+    // last pencil load of the workgroup has landed.  Measured per order (profiles/r02_stage_a_variants.txt): 8 % faster at
+    // N = 5, 4 % at N = 3, 7 % slower at N = 6, even at N = 4 -- hence StageA::MODE.
+        static_for<0, DIM>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
+            const bool wave_mine = it > 0 ? grp == D : (wave >= D * W0 && wave < (D + 1) * W0);      // wave-uniform
+            if (wave_mine) {
+                constexpr int ps = G::pstride(D);
+                constexpr bool WIDE = (ps == 1) && (N % 2 == 0);
+                const int k0 = (wave - D * W0) * 64 + (tid & 63);
+                const bool mine = it > 0 ? d_task >= 0 : k0 < CPB * NF;
+                const int c = it > 0 ? d_task / NN : k0 / NF;
+                const int r = it > 0 ? d_task - c * NN : k0 - c * NF;
+                const int l = it > 0 ? r / NF : 0, t = it > 0 ? r - l * NF : r;
+                const int off = mine ? c * CS + l * SL + G::pbase(D, t) : 0;
+                double qw[N][NV];
+                if (mine) {
+                    if constexpr (WIDE) {
+#pragma unroll
+                        for (int v = 0; v < NV; v++)
+#pragma unroll
+                            for (int jj = 0; jj < N / 2; jj++) {
+                                const double2 t2 = EXA_LD2(off + v * NTS * SL + 2 * jj);
+                                qw[2 * jj][v] = t2.x;
+                                qw[2 * jj + 1][v] = t2.y;
+                            }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < N; j++)
+#pragma unroll
+                            for (int v = 0; v < NV; v++) qw[j][v] = EXA_LD(off + v * NTS * SL + j * ps);
+                    }
+                }
+                EXA_STAMP(1);
+                __syncthreads();                                 // (R) every read of Q is done
+                EXA_STAMP(2);
+                if (mine) {
+                    double s[N][NV];
+                    pencil_sums<D, N, PDE>(qw, ops_here<N>(ops_raw)->DEO, idx[D], s);
+                    {
+                    if constexpr (WIDE) {
+#pragma unroll
+                        for (int v = 0; v < NV; v++)
+#pragma unroll
+                            for (int ii = 0; ii < N / 2; ii++)
+                                EXA_ST2(off + D * ASZ + v * NTS * SL + 2 * ii, s[2 * ii][v], s[2 * ii + 1][v]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < N; i++)
+#pragma unroll
+                            for (int v = 0; v < NV; v++) EXA_ST(off + D * ASZ + v * NTS * SL + i * ps, s[i][v]);
+                    }
+                    }
+                }
+            }
+        });
+        if (it == 0 && wave >= DIM * W0) __syncthreads();        // (R) for the waves without a pencil in iteration 0
+    } else {
         double s[N][NV];                                         // direction 0 keeps its sums over the barrier
         int zoff = 0;
         bool did_x = false;
@@ -326,17 +470,27 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             // l = 0 pencils are computed (the time update below then uses the row sums of T).  They are
             // packed on W0 waves per direction at the front of the workgroup, i.e. on different SIMDs
             // (the first waves of the three groups would share one SIMD and serialise).
-            constexpr int W0 = (CPB * NF + 63) / 64;
-            const int wave = tid >> 6;
             const int k0 = (wave - D * W0) * 64 + (tid & 63);      // iteration-0 task of this lane for direction D
-            const bool mine = it > 0 ? (grp == D && d_task >= 0) : (wave >= D * W0 && wave < (D + 1) * W0 && k0 < CPB * NF);
-            if (mine EXA_ABL_COND_SKIP_D) {
+            const bool wave_mine = it > 0 ? grp == D : (wave >= D * W0 && wave < (D + 1) * W0);       // wave-uniform
+            const bool mine = wave_mine && (it > 0 ? d_task >= 0 : k0 < CPB * NF);
+            // MODE 2: whole waves enter (every wave of the direction counts itself in exactly once); lanes without a pencil
+            // compute on pencil 0 and store nothing
+            if ((SA::MODE == 2 ? wave_mine : mine) EXA_ABL_COND_SKIP_D) {
                 constexpr int ps = G::pstride(D);
-                const int c = it > 0 ? d_task / NN : k0 / NF;
-                const int r = it > 0 ? d_task - c * NN : k0 - c * NF;
+                const int c = !mine ? 0 : it > 0 ? d_task / NN : k0 / NF;
+                const int r = !mine ? 0 : it > 0 ? d_task - c * NN : k0 - c * NF;
                 const int l = it > 0 ? r / NF : 0, t = it > 0 ? r - l * NF : r;
                 if constexpr (D == 0) did_x = true;
                 const int off = c * CS + l * SL + G::pbase(D, t);
+                // MODE 2, y / z waves: count this wave in once its last pencil load is issued (the LDS serves a wave's
+                // requests in order: when the add executes, the reads before it have been performed)
+                auto reads_done = [&]() {
+                    if constexpr (SA::MODE == 2 && D > 0) {
+                        asm volatile("" ::: "memory");
+                        if ((tid & 63) == 0) (void)__hip_atomic_fetch_add(q_readers, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        asm volatile("" ::: "memory");
+                    }
+                };
                 // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs --
                 // s_i -+ s_{N-1-i} from F_j +- F_{N-1-j}; odd N: the middle node and the middle row on top.
                 // (tried in round 2, measured and left as opt-in macros: the whole operator in SGPRs first -- one batch, one
@@ -364,6 +518,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             qw[2 * jj][v] = t2.x;
                             qw[2 * jj + 1][v] = t2.y;
                         }
+                    reads_done();
                 } else {
 #ifdef EXA_A_LOADS_FIRST   // (every load of the pencil first: 0.5 % slower at N = 6, more live registers)
                     // in the order the even-odd form consumes them: node j, its mirror, next j
@@ -374,6 +529,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             qw[j][v] = EXA_LD(off + v * NTS * SL + j * ps);
                             if (j != N - 1 - j) qw[N - 1 - j][v] = EXA_LD(off + v * NTS * SL + (N - 1 - j) * ps);
                         }
+                    reads_done();
 #endif
                 }
                 {
@@ -395,6 +551,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                                 qw[j][v] = EXA_LD(off + v * NTS * SL + j * ps);
                                 qw[jm][v] = EXA_LD(off + v * NTS * SL + jm * ps);
                             }
+                            if (j == H - 1 && N % 2 == 0) reads_done();
                         }
 #endif
                         PDE::aux_fast(qw[j], aa);
@@ -428,6 +585,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         if constexpr (!WIDE) {
 #pragma unroll
                             for (int v = 0; v < NV; v++) qw[H][v] = EXA_LD(off + v * NTS * SL + H * ps);
+                            reads_done();
                         }
 #endif
                         PDE::aux_fast(qw[H], aa);
@@ -450,22 +608,44 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         }
                 }
                 if constexpr (D > 0 && WIDE) {
+                    if (mine) {
 #pragma unroll
                     for (int v = 0; v < NV; v++)
 #pragma unroll
                         for (int ii = 0; ii < N / 2; ii++)
                             EXA_ST2(off + D * ASZ + v * NTS * SL + 2 * ii, s[2 * ii][v], s[2 * ii + 1][v]);
+                    }
                 } else
                 if constexpr (D > 0) {
+                    if (mine) {
 #pragma unroll
                     for (int i = 0; i < N; i++)
 #pragma unroll
                         for (int v = 0; v < NV; v++) EXA_ST(off + D * ASZ + v * NTS * SL + i * ps, s[i][v]);
+                    }
+                } else if constexpr (SA::MODE == 2) {
+                    // Q := S_x as soon as every y / z wave of this iteration has read its pencils -- beside their arithmetic
+                    const int target = (DIM - 1) * W0 + (DIM - 1) * SA::WPD * it;     // y / z waves counted in up to this iteration
+                    // (the sums first: without the pin the compiler polls before the arithmetic)
+#pragma unroll
+                    for (int i = 0; i < N; i++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) asm volatile("" : "+v"(s[i][v]) :: "memory");
+                    EXA_STAMP(1);
+                    while (__hip_atomic_load(q_readers, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                    EXA_STAMP(2);
+                    if (mine) {
+#pragma unroll
+                        for (int i = 0; i < N; i++)
+#pragma unroll
+                            for (int v = 0; v < NV; v++) EXA_ST(off + v * NTS * SL + i * ps, s[i][v]);
+                    }
                 } else {
                     zoff = off;
                 }
             }
         });
+        if constexpr (SA::MODE == 0) {
         EXA_STAMP(1);
         __syncthreads();                                             // (1) every read of Q is done; S_y (A) and S_z (B) are complete
         EXA_STAMP(2);
@@ -572,6 +752,71 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 #endif
             }
         });
+        }
+    }
+    if constexpr (SA::MODE != 0) {
+        EXA_STAMP(10);
+        __syncthreads();                                             // (1) S_x (over Q), S_y (A), S_z (B) are complete
+        EXA_STAMP(11);
+        // ---- time update, one straight-line copy per direction group
+        static_for<0, DIM>([&](auto gc) {
+            constexpr int GI = decltype(gc)::value;
+            constexpr int CNT = tcnt(GI), V0 = tv0(GI);
+            if constexpr (CNT > 0) {
+                if (grp == GI && t_node) {
+                    if (it == 0) {                                   // the iterate was constant in time: level 0, row sums of T
+                        double Ts[N];
+                        sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++) {
+                            const int o = toff + ((V0 + vv) * NTS + 0) * SL;
+                            double x = EXA_LD(o) + EXA_LD(o + ASZ);
+                            if constexpr (DIM == 3) x += EXA_LD(o + 2 * ASZ);
+                            const double uv = um[vv];
+#pragma unroll
+                            for (int lp = 0; lp < N; lp++) EXA_ST(toff + ((V0 + vv) * NTS + lp) * SL, fma(Ts[lp], x, uv));
+                        }
+                    } else {
+                        double S[CNT][N], Sy[CNT][N], Sz[CNT][N];   // every load first, then the adds
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++)
+#pragma unroll
+                            for (int l = 0; l < N; l++) {
+                                const int o = toff + ((V0 + vv) * NTS + l) * SL;
+                                S[vv][l] = EXA_LD(o);
+                                Sy[vv][l] = EXA_LD(o + ASZ);
+                                if constexpr (DIM == 3) Sz[vv][l] = EXA_LD(o + 2 * ASZ);
+                            }
+#pragma unroll
+                        for (int vv = 0; vv < CNT; vv++)
+#pragma unroll
+                            for (int l = 0; l < N; l++) {
+                                S[vv][l] += Sy[vv][l];
+                                if constexpr (DIM == 3) S[vv][l] += Sz[vv][l];
+                            }
+                        constexpr int RH = (N + 1) / 2;
+                        static_for<0, 2>([&](auto hc) {
+                            constexpr int half = decltype(hc)::value;
+                            constexpr int R0 = half * RH, RN = (half == 0) ? RH : N - RH;
+                            double Tm[RN * N];
+                            sload<RN * N>(step_here<N>(step_raw)->Tdt + R0 * N, Tm);
+#pragma unroll
+                            for (int vv = 0; vv < CNT; vv++) {
+                                const double uv = um[vv];
+#pragma unroll
+                                for (int r = 0; r < RN; r++) {
+                                    double acc = uv;
+#pragma unroll
+                                    for (int l = 0; l < N; l++) EXA_FMA(acc, Tm[r * N + l], S[vv][l]);
+                                    EXA_ST(toff + ((V0 + vv) * NTS + R0 + r) * SL, acc);
+                                }
+                            }
+                        });
+                    }
+                }
+            }
+        });
+    }
         EXA_STAMP(3);
         __syncthreads();                                             // (3) the new iterate is in Q
         EXA_STAMP(4);
