@@ -265,6 +265,12 @@ def run_cfg2(a, torch, exa, world, rank, local):
     if world == 1:
         ach = work["flop_a"] / ta / 1e12
         traffic, src = read_traffic("stage_a_traffic.json", cells=a.cells, order=a.order)
+        pmc = {}
+        pf = os.path.join(ROOT, "profiles", "stage_a_pmc.json")          # SQ counters of the same kernel (48^3 cells): not measured in this run
+        if os.path.exists(pf) and a.order == 5:
+            rec = json.load(open(pf))
+            pmc = {"valu_busy": rec["valu_issue_frac"], "lds_busy": rec["lds_array_busy_frac"], "mfma_busy": 0.0,
+                   "busy_source": "profiles/stage_a_pmc.json (rocprofv3 --pmc SQ_* passes at 48^3 cells)"}
         out["roofline"] = {"kernel": "dg_stage_a_kernel<3,%d,Euler>" % N, "bound": "fp64-valu", "achieved": ach,
                            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_source": src, "launch_ms": ta * 1e3, "launches_per_step": per_step, "flop_per_launch": work["flop_a"],
@@ -272,6 +278,7 @@ def run_cfg2(a, torch, exa, world, rank, local):
                            "hbm_frac_of_measured_copy": work["bytes_a"] / ta / 1e9 / HBM_MEASURED_GBS,
                            "note": "fp64-compute-bound (48 FLOP/B): priced against the 78.6 TFLOP/s fp64 vector peak; the kernel "
                                    "issues no MFMA (fp64 MFMA has the same peak and fills 28 % of a tile at N = 6)"}
+        out["roofline"].update(pmc)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dg(3, N, N)
             out["cpu_reference_fv"] = cpu_reference_fv()
