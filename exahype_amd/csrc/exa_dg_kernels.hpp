@@ -258,17 +258,15 @@ template <int DIM, int N, class PDE, int CPB> struct StageA {
     static constexpr int NT = DIM * WPD * 64;                // threads per workgroup
     static constexpr size_t STEP_OFF = (PERM_OFF + sizeof(int) * DIM * WPD * 64 + 15) / 16 * 16;
     static constexpr size_t IMAGE_BYTES = STEP_OFF + sizeof(DgStepOps<N>);
-    // which form of the Picard loop (see the kernel): measured per order on 3-D Euler, 64^3 cells
+    // which form of the Picard loop (see the kernel): measured per order on 3-D Euler, 64^3 cells (profiles/r02_stage_a_variants.txt)
     //   0 "late":  x group stores S_x over Q after barrier (1), barrier (2), time update
     //   1 "early": every pencil loaded, barrier (R), sums stored at once, barrier (1), time update
-    //   2 "flag":  as 0, but the x group waits for a count of the y / z waves whose pencil loads are done instead of for
-    //              barrier (1), and stores S_x beside their arithmetic; barrier (2) is gone
+    // (a third form -- the x group waits for a count of the y / z waves whose loads are done instead of for a barrier -- timed
+    //  like 0 at N = 6 and 2 % better than 1 at N = 5; not kept: see the profile note and commit a7e35b6)
 #if defined(EXA_A_EARLY_STORE)
     static constexpr int MODE = 1;
 #elif defined(EXA_A_LATE_STORE)
     static constexpr int MODE = 0;
-#elif defined(EXA_A_FLAG)
-    static constexpr int MODE = 2;
 #else
     static constexpr int MODE = (DIM == 3 && (N == 5 || N == 3)) ? 1 : 0;
 #endif
@@ -301,8 +299,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // rows 0, 1: this block's cells | the next block's (ping-pong); rows 2..7: box coordinates of the lane's slot and their step
     // (one static array of 64 * CPB bytes: the dynamic LDS base behind it stays 16-byte aligned for the 16-byte accesses)
-    __shared__ long cell_ids[SA::MODE == 2 ? 10 : 8][CPB];     // (MODE 2: row 8 holds the reader count, as an int)
-    [[maybe_unused]] int* q_readers = reinterpret_cast<int*>(&cell_ids[SA::MODE == 2 ? 8 : 0][0]);
+    __shared__ long cell_ids[8][CPB];
 
     const int tid = threadIdx.x;
     EXA_STAMP_INIT();
@@ -363,9 +360,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
     for (; blk < nblocks; blk += gridDim.x, par ^= 1) {
     const long* cell_id = cell_ids[par];
     {
-        if constexpr (SA::MODE == 2) {
-            if (tid == 0) *q_readers = 0;
-        }
         if (tid < CPB) {                                         // the next block's slot of this lane
             long cx = cell_ids[2][tid], cy = cell_ids[3][tid], cz = cell_ids[4][tid];
             cz += cell_ids[7][tid];
@@ -398,9 +392,9 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 
     // ---- Picard iterations (A.2):  q <- u - dt * T * sum_d (1/dx_d) D_d f_d(q)
     for (int it = 0; it < n_it; it++) {
+    if constexpr (SA::MODE == 1) {
     constexpr int W0 = (CPB * NF + 63) / 64;                     // iteration 0: the l = 0 pencils, packed on W0 waves per direction
     const int wave = tid >> 6;
-    if constexpr (SA::MODE == 1) {
     // Form with an early "reads done" barrier: every lane loads its whole pencil, barrier (R), then computes and stores its
     // sums at once -- x over Q (nobody reads Q any more), y -> A, z -> B.  The serial phase of the other form (x group stores
     // after barrier (1) while the others wait, then barrier (2)) is gone; its price is that no flux is evaluated before the
@@ -470,27 +464,17 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             // l = 0 pencils are computed (the time update below then uses the row sums of T).  They are
             // packed on W0 waves per direction at the front of the workgroup, i.e. on different SIMDs
             // (the first waves of the three groups would share one SIMD and serialise).
+            constexpr int W0 = (CPB * NF + 63) / 64;
+            const int wave = tid >> 6;
             const int k0 = (wave - D * W0) * 64 + (tid & 63);      // iteration-0 task of this lane for direction D
-            const bool wave_mine = it > 0 ? grp == D : (wave >= D * W0 && wave < (D + 1) * W0);       // wave-uniform
-            const bool mine = wave_mine && (it > 0 ? d_task >= 0 : k0 < CPB * NF);
-            // MODE 2: whole waves enter (every wave of the direction counts itself in exactly once); lanes without a pencil
-            // compute on pencil 0 and store nothing
-            if ((SA::MODE == 2 ? wave_mine : mine) EXA_ABL_COND_SKIP_D) {
+            const bool mine = it > 0 ? (grp == D && d_task >= 0) : (wave >= D * W0 && wave < (D + 1) * W0 && k0 < CPB * NF);
+            if (mine EXA_ABL_COND_SKIP_D) {
                 constexpr int ps = G::pstride(D);
-                const int c = !mine ? 0 : it > 0 ? d_task / NN : k0 / NF;
-                const int r = !mine ? 0 : it > 0 ? d_task - c * NN : k0 - c * NF;
+                const int c = it > 0 ? d_task / NN : k0 / NF;
+                const int r = it > 0 ? d_task - c * NN : k0 - c * NF;
                 const int l = it > 0 ? r / NF : 0, t = it > 0 ? r - l * NF : r;
                 if constexpr (D == 0) did_x = true;
                 const int off = c * CS + l * SL + G::pbase(D, t);
-                // MODE 2, y / z waves: count this wave in once its last pencil load is issued (the LDS serves a wave's
-                // requests in order: when the add executes, the reads before it have been performed)
-                auto reads_done = [&]() {
-                    if constexpr (SA::MODE == 2 && D > 0) {
-                        asm volatile("" ::: "memory");
-                        if ((tid & 63) == 0) (void)__hip_atomic_fetch_add(q_readers, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        asm volatile("" ::: "memory");
-                    }
-                };
                 // even-odd form of the centro-antisymmetric D (DgOps::DEO): half the FMAs --
                 // s_i -+ s_{N-1-i} from F_j +- F_{N-1-j}; odd N: the middle node and the middle row on top.
                 // (tried in round 2, measured and left as opt-in macros: the whole operator in SGPRs first -- one batch, one
@@ -518,7 +502,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             qw[2 * jj][v] = t2.x;
                             qw[2 * jj + 1][v] = t2.y;
                         }
-                    reads_done();
                 } else {
 #ifdef EXA_A_LOADS_FIRST   // (every load of the pencil first: 0.5 % slower at N = 6, more live registers)
                     // in the order the even-odd form consumes them: node j, its mirror, next j
@@ -529,7 +512,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             qw[j][v] = EXA_LD(off + v * NTS * SL + j * ps);
                             if (j != N - 1 - j) qw[N - 1 - j][v] = EXA_LD(off + v * NTS * SL + (N - 1 - j) * ps);
                         }
-                    reads_done();
 #endif
                 }
                 {
@@ -551,7 +533,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                                 qw[j][v] = EXA_LD(off + v * NTS * SL + j * ps);
                                 qw[jm][v] = EXA_LD(off + v * NTS * SL + jm * ps);
                             }
-                            if (j == H - 1 && N % 2 == 0) reads_done();
                         }
 #endif
                         PDE::aux_fast(qw[j], aa);
@@ -585,7 +566,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         if constexpr (!WIDE) {
 #pragma unroll
                             for (int v = 0; v < NV; v++) qw[H][v] = EXA_LD(off + v * NTS * SL + H * ps);
-                            reads_done();
                         }
 #endif
                         PDE::aux_fast(qw[H], aa);
@@ -608,44 +588,22 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         }
                 }
                 if constexpr (D > 0 && WIDE) {
-                    if (mine) {
 #pragma unroll
                     for (int v = 0; v < NV; v++)
 #pragma unroll
                         for (int ii = 0; ii < N / 2; ii++)
                             EXA_ST2(off + D * ASZ + v * NTS * SL + 2 * ii, s[2 * ii][v], s[2 * ii + 1][v]);
-                    }
                 } else
                 if constexpr (D > 0) {
-                    if (mine) {
 #pragma unroll
                     for (int i = 0; i < N; i++)
 #pragma unroll
                         for (int v = 0; v < NV; v++) EXA_ST(off + D * ASZ + v * NTS * SL + i * ps, s[i][v]);
-                    }
-                } else if constexpr (SA::MODE == 2) {
-                    // Q := S_x as soon as every y / z wave of this iteration has read its pencils -- beside their arithmetic
-                    const int target = (DIM - 1) * W0 + (DIM - 1) * SA::WPD * it;     // y / z waves counted in up to this iteration
-                    // (the sums first: without the pin the compiler polls before the arithmetic)
-#pragma unroll
-                    for (int i = 0; i < N; i++)
-#pragma unroll
-                        for (int v = 0; v < NV; v++) asm volatile("" : "+v"(s[i][v]) :: "memory");
-                    EXA_STAMP(1);
-                    while (__hip_atomic_load(q_readers, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-                    EXA_STAMP(2);
-                    if (mine) {
-#pragma unroll
-                        for (int i = 0; i < N; i++)
-#pragma unroll
-                            for (int v = 0; v < NV; v++) EXA_ST(off + v * NTS * SL + i * ps, s[i][v]);
-                    }
                 } else {
                     zoff = off;
                 }
             }
         });
-        if constexpr (SA::MODE == 0) {
         EXA_STAMP(1);
         __syncthreads();                                             // (1) every read of Q is done; S_y (A) and S_z (B) are complete
         EXA_STAMP(2);
@@ -752,7 +710,6 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 #endif
             }
         });
-        }
     }
     if constexpr (SA::MODE != 0) {
         EXA_STAMP(10);
