@@ -215,7 +215,9 @@ def read_traffic(name, **match):
 def run_cfg2(a, torch, exa, world, rank, local):
     """BASELINE configs[2] / configs[3]: 3-D Euler p=5, full predictor + corrector, 128^3 cells per GPU."""
     import torch.distributed as dist
-    part = exa.CartesianPartition(world, rank, 3) if world > 1 else None
+    selfx = world == 1 and a.self_exchange           # rehearsal: the sharded step on one GPU, periodic wrap through RCCL send/recv to self
+    part = exa.CartesianPartition(world, rank, 3, exchange_self=(0, 1, 2) if selfx else ()) if (world > 1 or selfx) else None
+    sharded = part is not None
     pdims = part.pdims if part else [1, 1, 1]
     coords = part.coords if part else [0, 0, 0]
     N = a.order + 1
@@ -237,7 +239,7 @@ def run_cfg2(a, torch, exa, world, rank, local):
         s.step(dt)
     sync()
     s.stage_a_events = []                  # stage-A launch durations: events on the stream the kernels are launched on
-    if world > 1:
+    if sharded:
         s.exchange_events = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -285,7 +287,7 @@ def run_cfg2(a, torch, exa, world, rank, local):
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dg(3, N, N)
             out["cpu_reference_fv"] = cpu_reference_fv()
-    else:
+    if sharded:
         # the exchange (pack + RCCL send/recv) on the comm stream against the interior stage A on the compute stream
         ex, ov = [], []
         for ready, c0, c1, i0, i1 in s.exchange_events:
@@ -299,6 +301,8 @@ def run_cfg2(a, torch, exa, world, rank, local):
         dist.all_gather(allv, mine)
         names = [None] * world
         dist.all_gather_object(names, "%s:%d" % (torch.cuda.get_device_name(local), local))
+        if selfx:
+            out["rehearsal"] = "sharded step on one GPU: shell / interior boxes, packed faces, ncclSend / ncclRecv to self, stage B on ghost buffers"
         out["rccl_ranks"] = dist.get_world_size()
         out["backend"] = dist.get_backend()
         out["devices"] = names
@@ -445,6 +449,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path with host-staged exchange")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--self-exchange", action="store_true",
+                    help="rehearsal only (--gpus 1, cfg2): run the SHARDED step on one GPU, the periodic wrap going through RCCL send/recv to self")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -456,6 +462,12 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d" % (a.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # stdout carries ONE line: the JSON record.  Libraries write there too (RCCL prints a version table on rank 0 when its
+    # communicator comes up), so file descriptor 1 is pointed at stderr for the run and the record goes to the saved one.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -474,6 +486,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(a.backend)
+    elif a.self_exchange:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port,
+                                device_id=torch.device("cuda", local))
 
     if a.config == "cfg2":
         out = run_cfg2(a, torch, exa, world, rank, local)
@@ -484,8 +503,9 @@ def main():
     else:
         out = run_fv_ref(a, torch, exa, local)
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or a.self_exchange:
         dist.destroy_process_group()
 
 

@@ -92,7 +92,10 @@ class CartesianPartition:
     """Process grid for `world` ranks in `dim` dimensions (8 -> 2x2x2, 4 -> 2x2x1,
     2 -> 2x1x1), rank = row-major index; periodic neighbours."""
 
-    def __init__(self, world, rank, dim, pdims=None):
+    def __init__(self, world, rank, dim, pdims=None, exchange_self=()):
+        # exchange_self: directions of process-grid extent 1 whose periodic wrap goes through the exchange anyway (a rank is
+        # its own neighbour: RCCL send/recv to self) -- lets ONE GPU run the sharded step over the real transport
+        self.exchange_self = tuple(int(d) for d in exchange_self)
         if pdims is None:
             pdims = [1] * dim
             w, a = world, 0
@@ -117,7 +120,7 @@ class CartesianPartition:
         return self.rank_of(c)
 
     def partitioned(self, d):
-        return self.pdims[d] > 1
+        return self.pdims[d] > 1 or d in self.exchange_self
 
     def shell_and_interior(self, nc):
         """Disjoint cell boxes: the layers touching a partitioned block face, and the rest."""
@@ -262,7 +265,7 @@ class AderDgSolver:
         # per sharded step.  None = off: the product path records nothing.
         self.stage_a_events = None
         self.exchange_events = None
-        if part is not None and part.world > 1:
+        if part is not None and any(part.partitioned(d) for d in range(dim)):
             self.halo = HaloExchange(part, self.nc, self.ts, self.dev, stage_through_host=backend_is_gloo)
             self.comm_stream = torch.cuda.Stream(device=self.dev)
             self.shell, self.interior = part.shell_and_interior(self.nc)

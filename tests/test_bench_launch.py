@@ -67,3 +67,19 @@ def test_single_gpu_line_has_roofline_and_config_variants():
         assert r.returncode == 0, r.stderr[-3000:]
         o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
         assert o["roofline"]["bound"] == bound and o["finite"] and o["value"] > 0
+
+
+@pytest.mark.gpu
+def test_self_exchange_rehearsal_runs_the_sharded_step_over_rccl():
+    """`--self-exchange`: one rank on the nccl (= RCCL) backend, its own neighbour in every direction -- the sharded step with its
+    measurement fields over the real transport.  stdout must hold the JSON line and nothing else (RCCL prints a version table when a
+    communicator comes up: bench.py keeps it off file descriptor 1)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--self-exchange", "--cells", "8", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"] == "nccl" and "rehearsal" in out
+    assert out["finite"] and out["exchange_ms"] > 0 and 0.0 <= out["overlap_frac"] <= 1.0
+    assert out["roofline"]["launches_per_step"] >= 2           # shell boxes + interior box

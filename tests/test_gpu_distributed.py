@@ -84,6 +84,50 @@ def test_sharded_step_equals_global_oracle(tmp_path, N, nc, pdims):
     _run_ranks(tmp_path, WORKER % dict(root=ROOT, N=N, nc=nc, pdims=pdims), world)
 
 
+RCCL_SELF_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from exahype_amd import solvers as exa
+import oracle
+from oracle.dg_operators import operators
+from tests.util import euler_dg_state
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)            # RCCL, one rank: its own neighbour in every direction
+dim, N, nc = 3, %(N)d, %(nc)r
+part = exa.CartesianPartition(1, 0, dim, exchange_self=(0, 1, 2))
+u = euler_dg_state(tuple(nc) + (N,) * dim, seed=9)
+dx = [1.0 / c for c in nc]
+dt = 0.02 * min(dx) / (2 * N - 1)
+s = exa.AderDgSolver(dim, N, nc, dx=dx, part=part)               # device buffers go to ncclSend / ncclRecv as they are
+assert s.halo is not None and all(g is not None and g.is_cuda for g in s.halo.ghost)
+s.exchange_events = []
+s.upload(u)
+plain = exa.AderDgSolver(dim, N, nc, dx=dx)
+plain.upload(u)
+ref = u.reshape(-1).copy()
+for _ in range(2):
+    s.step(dt)
+    plain.step(dt)
+    ref = oracle.aderdg_step(ref, dt, dx, operators(N), dim, N, 5, oracle.PDE_EULER, N, tuple(nc))
+torch.cuda.synchronize()
+got = s.download()
+err = np.max(np.abs(got - ref.reshape(u.shape))) / np.max(np.abs(ref))
+assert err < 1e-10, err
+assert np.array_equal(got, plain.download())                     # shell + interior + ghost buffers == one periodic block, bit for bit
+assert len(s.exchange_events) == 2
+dist.barrier(); dist.destroy_process_group()
+print("rccl self exchange rel err", err)
+'''
+
+
+def test_sharded_step_over_rccl_send_recv_to_self(tmp_path):
+    """The one exchange the box's single GPU allows over the real transport: a process group of ONE rank on the nccl (= RCCL) backend,
+    every direction wrapped through HaloExchange (ncclSend / ncclRecv to self inside one group call).  cfg 3's order; the result must equal
+    both the oracle and the un-sharded periodic block."""
+    _run_ranks(tmp_path, RCCL_SELF_WORKER % dict(root=ROOT, N=6, nc=(3, 2, 2)), 1)
+
+
 LIM_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
