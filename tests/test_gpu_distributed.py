@@ -1,7 +1,8 @@
 """The sharded ADER-DG step (boundary shell first, face-trace exchange on a second stream, interior
 overlapped) on real kernels: 2 or 4 ranks share cuda:0 and exchange over gloo (host-staged); the result
-must equal the oracle's step of the whole periodic grid.  (RCCL itself needs one GPU per rank; the
-driver's 8-GPU run exercises that backend with the same code path.)  cfg 3 runs at its own order
+must equal the oracle's step of the whole periodic grid.  (RCCL between ranks needs one GPU per rank: the
+driver's 8-GPU run exercises that; what the one-GPU box can do over the real transport is a rank that is its own
+periodic neighbour -- the two *_over_rccl_send_recv_to_self tests below.)  cfg 3 runs at its own order
 (N = 6: the persistent LDS-resident stage A on shell / interior boxes, the dense stage B with ghost
 buffers in one and in two directions), cfg 4 at its own (N = 8: level-streamed stage A + 17^3 FV patches)."""
 import os
@@ -175,3 +176,48 @@ print("rank", rank, "rel err", err)
 def test_sharded_limited_step_equals_global_oracle(tmp_path, dim, N, nc, pdims):
     """cfg 4 across ranks: troubled cells at a block face take their FV halo from the neighbour block's subcell layer."""
     _run_ranks(tmp_path, LIM_WORKER % dict(root=ROOT, dim=dim, N=N, nc=nc, pdims=pdims), 2)
+
+
+RCCL_SELF_LIM_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from exahype_amd import solvers as exa
+import oracle
+from oracle import aderdg_numpy as A
+from oracle.dg_operators import operators
+from oracle.limiter_numpy import limited_step
+from tests.util import euler_dg_state
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+dim, N, nc = 3, %(N)d, %(nc)r
+part = exa.CartesianPartition(1, 0, dim, exchange_self=(0, 1, 2))
+u = euler_dg_state(tuple(nc) + (N,) * dim, seed=7)
+dx = [1.0 / nc[0]] * dim
+dt = 0.02 * dx[0] / (2 * N - 1)
+mask = np.random.default_rng(11).random(nc) < 0.4
+mask[(0,) * dim] = True
+s = exa.AderDgSolver(dim, N, nc, dx=dx, part=part)
+lim = exa.SubcellLimiter(s)
+assert lim.hx_layer is not None and not lim.hx_layer.stage      # subcell layers travel as device buffers
+s.upload(u)
+ops = operators(N)
+def fv(patch, dt, h):
+    return oracle.fv_corrected(patch[None], dt, h, dim, patch.shape[0] - 2, 1, 5, 0, 1, oracle.PDE_EULER)[0]
+ref = u.copy()
+for _ in range(2):
+    n = lim.step(dt, mask)
+    assert n == int(mask.sum())
+    ref = limited_step(ref, mask, dt, dx, ops, A.Euler(), fv)
+torch.cuda.synchronize()
+err = np.max(np.abs(s.download() - ref)) / np.max(np.abs(ref))
+assert err < 1e-10, err
+dist.barrier(); dist.destroy_process_group()
+print("rccl self exchange, limited step: rel err", err)
+'''
+
+
+def test_sharded_limited_step_over_rccl_send_recv_to_self(tmp_path):
+    """cfg 4's order (p = 7, 17^3 FV patches) with both limiter exchanges (troubled flags, subcell layers) and the trace exchange over RCCL
+    send/recv to self."""
+    _run_ranks(tmp_path, RCCL_SELF_LIM_WORKER % dict(root=ROOT, N=8, nc=(2, 1, 2)), 1)
