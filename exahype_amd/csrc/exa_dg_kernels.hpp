@@ -96,6 +96,7 @@ template <int N> __global__ void dg_step_ops_kernel(const DgOps<N>* __restrict__
 // buffer of their own (never an output element); the production kernel executes no stamp.
 #ifdef EXA_STAMPS
 __device__ unsigned long long g_exa_stamps[48];
+__device__ unsigned long long g_exa_wg_span[2 * 1024];     // per workgroup: start and end on the constant-rate clock (load balance)
 #define EXA_STAMP(slot)                                                                         \
     do {                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                      \
@@ -107,9 +108,11 @@ __device__ unsigned long long g_exa_stamps[48];
     } while (0)
 #define EXA_STAMP_INIT()                                                                        \
     unsigned long long t_prev_, acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_exa_wg_span[2 * blockIdx.x] = wall_clock64();  \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_)::"memory")
 #define EXA_STAMP_FLUSH()                                                                       \
     do {                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_exa_wg_span[2 * blockIdx.x + 1] = wall_clock64(); \
         if (bt == 0)                                                                            \
             for (int k_ = 0; k_ < 12; k_++) atomicAdd(&g_exa_stamps[grp * 12 + k_], acc_[k_]);  \
     } while (0)

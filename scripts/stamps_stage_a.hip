@@ -2,6 +2,7 @@
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DEXA_STAMPS -I exahype_amd/csrc scripts/stamps_stage_a.hip -o scripts/stamps_stage_a
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 #include "exa_dg_kernels.hpp"
 using namespace exa;
 int main() {
@@ -48,6 +49,23 @@ int main() {
         for (int k = 0; k < 12; k++) printf("   %-18s %9.0f %9.0f %9.0f\n", names[k], (double)z[k] / ncells, (double)z[12 + k] / ncells, (double)z[24 + k] / ncells);
         double tot = 0; for (int k = 0; k < 12; k++) tot += z[k];
         printf("   total              %9.0f\n", tot / ncells);
+#ifdef EXA_STAMPS
+        {   // load balance of the persistent grid: per-workgroup start / end on the constant-rate clock (100 MHz ticks)
+            std::vector<unsigned long long> sp(2 * 1024);
+            hipMemcpyFromSymbol(sp.data(), HIP_SYMBOL(g_exa_wg_span), sp.size() * 8);
+            unsigned long long t0 = ~0ull, te_min = ~0ull, te_max = 0, ts_max = 0; double dsum = 0, dmin = 1e30, dmax = 0;
+            for (int b = 0; b < 256; b++) { t0 = std::min(t0, sp[2 * b]); }
+            for (int b = 0; b < 256; b++) {
+                const double d = (double)(sp[2 * b + 1] - sp[2 * b]);
+                dsum += d; dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+                te_min = std::min(te_min, sp[2 * b + 1]); te_max = std::max(te_max, sp[2 * b + 1]); ts_max = std::max(ts_max, sp[2 * b]);
+            }
+            printf("workgroup spans (ticks of the constant clock): mean %.0f min %.0f max %.0f; last start %+lld, first end %lld, last end %lld after the first start\n",
+                   dsum / 256, dmin, dmax, (long long)(ts_max - t0), (long long)(te_min - t0), (long long)(te_max - t0));
+            double xs[8] = {0}; for (int b = 0; b < 256; b++) xs[b % 8] += (double)(sp[2 * b + 1] - sp[2 * b]) / 32;
+            printf("mean span per XCD (blockIdx %% 8):"); for (int x = 0; x < 8; x++) printf(" %.0f", xs[x]); printf("\n");
+        }
+#endif
     }
     return 0;
 }
