@@ -399,7 +399,11 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                     }
                 }
                 EXA_STAMP(6);
+#ifdef EXA_STREAM_BARRIER4
                 __syncthreads();
+#endif
+                // (no barrier here: the next load phase writes Q and the flux scalars at the owner's OWN node, which only this lane
+                //  read in the fold above; the derive phase that read them across lanes ended two barriers ago)
                 EXA_STAMP(7);
             }
             // ---- new iterate q_l' = u - dt * acc (u arrived in nxt[0]); the first level of each slot feeds the next
@@ -434,6 +438,9 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
         }
 
         // ---- time averages: each owner over its levels (OH == 2: the two parts meet in LDS): qbar | Fbar_d
+#ifndef EXA_STREAM_BARRIER4
+        __syncthreads();                                         // the last fold of every lane is done: the final image reuses Q / A / B
+#endif
         {
             double qb[NV], Fb[DIM][NV];
             const int o_off = opaque_v(o_off0);
