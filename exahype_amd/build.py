@@ -124,8 +124,12 @@ if __name__ == "__main__":
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("--variant", metavar="TAG", help="development aid: build lib/var_TAG/ with the macros given by --define")
     ap.add_argument("--define", action="append", default=[], metavar="MACRO", help="with --variant: -DMACRO (repeatable)")
+    ap.add_argument("--mllvm", action="append", default=[], metavar="OPT", help="with --variant: -mllvm -OPT (repeatable), e.g. amdgpu-sched-strategy=max-ilp")
     a = ap.parse_args()
     if a.variant:
-        print(build_variant(a.variant, ["-D" + d for d in a.define], a.jobs))
+        extra = ["-D" + d for d in a.define]
+        for o in a.mllvm:
+            extra += ["-mllvm", "-" + o]
+        print(build_variant(a.variant, extra, a.jobs))
     else:
         print(build(a.force, a.jobs, a.verbose))
