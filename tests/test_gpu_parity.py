@@ -147,7 +147,8 @@ def test_fv_rejects_bad_config(exa):
 
 # ---- ADER-DG -----------------------------------------------------------------------------------
 DG_CASES = [(2, 4, (5, 3)), (2, 2, (4, 4)), (2, 8, (2, 3)), (2, 5, (3, 2)), (2, 3, (2, 4)), (2, 7, (2, 2)), (3, 3, (3, 2, 2)), (3, 4, (2, 2, 3)), (3, 5, (2, 1, 3)), (3, 6, (2, 2, 2)),
-            (3, 7, (2, 1, 2)), (3, 8, (1, 2, 2))]       # N = 7, 8 in 3-D (cfg 4's p = 7): level-streamed stage A (exa_dg_stream.hpp)
+            (3, 7, (2, 1, 2)), (3, 8, (1, 2, 2)),       # N = 7, 8 in 3-D (cfg 4's p = 7): level-streamed stage A (exa_dg_stream.hpp)
+            (3, 2, (2, 2, 2)), (2, 6, (3, 2)), (3, 6, (1, 1, 1)), (2, 4, (1, 1))]     # lowest order; a single periodic cell (its own neighbour everywhere)
 
 
 def _ops(N):
