@@ -18,7 +18,12 @@ Recognised schemes
   "aderdg"               ADER-DG step on cells = patches (patch_size = order+1,
                          halo_size = 0, n_patches = number of cells) -- explicit
                          hint only; not expressible in the reference's surface.
-Anything else raises: there is no generic fallback and no CPU path.
+  "statements"           (automatic, for a statement list that is none of the above) lowered statement by statement
+                         as the reference's CPPPrinter does for every builder state -- one generated kernel per
+                         statement with the reference's ranges, strides and expression text (printers/lowering.py);
+                         refused, with the reason, if it calls opaque functions, reaches outside an array over its
+                         loop range (the reference's own examples do) or carries a dependence through a loop.
+Anything else raises: there is no CPU path.
 
 The user's opaque PDE terms (resolved at link time to `Unit test/Functions.cpp` in the
 reference) must be named: `pde=` selects a built-in device term set or a SympyPDE,
@@ -88,13 +93,25 @@ class HIPPrinter(CodePrinter):
         k = kernel
         self.device = device
         self._impl = None
+        self.lowering = None
         if scheme is None:
             t = _rusanov_template(k)
             if t is None or not _same_statements(k, t):
-                raise UnrecognisedKernel(
-                    "the statement list is not a scheme with a hand-written HIP kernel (recognised: the FV Rusanov "
-                    "patch update of examples/Batched_stateless.py; by hint: scheme='fv-rusanov' | 'aderdg'); "
-                    "there is no generic or CPU fallback")
+                # not a scheme with a fused hand-written kernel: lower it statement by statement, as the reference's printer
+                # does for every builder state (printers/lowering.py) -- or say why that cannot be done on a GPU
+                from .lowering import LoweringRefused, StatementLowering
+                try:
+                    self.lowering = StatementLowering(k, function_name)
+                except LoweringRefused as why:
+                    raise UnrecognisedKernel(
+                        "the statement list is not a scheme with a hand-written HIP kernel (recognised: the FV Rusanov "
+                        "patch update of examples/Batched_stateless.py; by hint: scheme='fv-rusanov' | 'aderdg') and cannot be "
+                        "lowered statement by statement: %s.  There is no CPU fallback" % why) from None
+                self.scheme = "statements"
+                self.pde, self.user_pde, self.pde_origin, self.n_picard = None, None, "none (no PDE term in the statements)", n_picard
+                self.code = ("// exahype_amd HIP lowering of `%s` (MI355X / gfx950): %d statements -> %d kernels, launched in order\n"
+                             % (function_name, len(k.LHS), len(self.lowering.statements))) + self.lowering.source()
+                return
             scheme = "fv-rusanov-faithful"
         if scheme not in ("fv-rusanov-faithful", "fv-rusanov", "aderdg"):
             raise ValueError("unknown scheme %r" % scheme)
@@ -213,6 +230,10 @@ class HIPPrinter(CodePrinter):
         """Bind libexahype_hip.so (built with hipcc if missing) and create the plan.  Raises without a GPU."""
         from .. import solvers
         k = self.kernel()
+        if self.scheme == "statements":
+            if self._impl is None:
+                self._impl = self.lowering.bind(self.device)
+            return self._impl
         if self.user_pde is not None and self.pde < 0:
             self.pde = self.user_pde.register()
         if self._impl is None:
@@ -225,10 +246,18 @@ class HIPPrinter(CodePrinter):
                                                      pde=self.pde, mode=mode, device=self.device)
         return self._impl
 
-    def run(self, Q, dt, h=1.0, dx=None, steps=1):
+    def run(self, Q, *consts, h=1.0, dx=None, steps=1):
         """FV: `time_step(Q, dt)` in place on a numpy array (staged) or CUDA tensor (resident).
-        ADER-DG: `steps` time steps of u (numpy AoS [cells][nodes][vars]) in place."""
+        ADER-DG: `steps` time steps of u (numpy AoS [cells][nodes][vars]) in place.
+        Lowered statement list: `time_step(Q, c0, c1, ...)` with the builder's input constants in declaration order."""
         impl = self.compile()
+        if self.scheme == "statements":
+            for _ in range(steps):
+                impl.run(Q, *consts)
+            return Q
+        if len(consts) != 1:
+            raise TypeError("run(Q, dt): this scheme takes the time step as its one constant")
+        dt = consts[0]
         if self.scheme == "aderdg":
             if dx is not None:
                 impl.dx = [float(x) for x in dx]

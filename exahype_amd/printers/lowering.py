@@ -1,0 +1,282 @@
+"""Statement-by-statement lowering of a KernelBuilder state to HIP kernels -- the generic path of the printer seam.
+
+The reference's `CPPPrinter` (`exahype/printers/CPPPrinter.py:84-137`) turns EVERY builder state into C++ text: temporaries on
+the heap, then one loop nest per statement (patch outermost; the axes over the interior `[H, P+H)`, or over the full `[0, P+2H)`
+along a statement's own direction when it has no `+-` offset; the variable loop `[0,1)`, `[0,n_real)` or `[0,n_real+n_aux)` by the
+smallest struct a statement touches), AoS strides.  `HIPPrinter` dispatches the statement lists it RECOGNISES to fused hand-written
+kernels; this module serves the others: one `__global__` kernel per statement with exactly the reference's ranges, strides and
+expression text (taken from this package's text-compatible `CPPPrinter`, which is pinned byte for byte against the reference's
+output), launched in statement order on one stream.  Temporaries live in HBM between the launches, as they live on the heap in the
+reference -- ten sweeps instead of one, correct rather than fast; the recognised schemes keep their fused kernels.
+
+A GPU runs a statement's loop nest in parallel and cannot be allowed to fault, so three things the reference's text leaves to
+luck are checked here, and a state that fails one is refused (`UnrecognisedKernel`), never "fixed":
+  * every array access of every statement lies inside its array for the whole loop range (the reference's own examples do
+    not: `items[1]` is addressed with `patch - 1`);
+  * a statement that writes an array reads that array only at the index it writes (no loop-carried dependence);
+  * no opaque function: the reference resolves `Flux(...)` to the user's host C++ at link time (`Unit test/Functions.h:2-4`),
+    a device kernel cannot -- such statement lists go through the recognised schemes with `pde=` / SymPy bodies.
+Integer powers, which SymPy builds from `a*a` and the reference prints as the Python `a**2`, are printed as products.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+
+import sympy
+from sympy import Indexed, Integer, Symbol
+from sympy.printing.str import StrPrinter
+from sympy.core.function import AppliedUndef
+
+from .CodePrinter import CodePrinter
+from .CPPPrinter import CPPPrinter
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN_DIR = os.path.join(HERE, "_user")
+
+
+class LoweringRefused(NotImplementedError):
+    """The builder state cannot be lowered statement by statement (reason in the message)."""
+
+
+class _CText(StrPrinter):
+    """str(expr) as the reference prints it, except a**n (n = 2..4), printed as the product it came from."""
+
+    def _print_Pow(self, expr, rational=False):
+        b, e = expr.args
+        if isinstance(e, Integer) and 2 <= int(e) <= 4:
+            t = self._print(b)
+            if not isinstance(b, (Indexed, Symbol)):
+                t = "(%s)" % t
+            return "*".join([t] * int(e))
+        return super()._print_Pow(expr, rational=rational)
+
+    def _print(self, expr, **kwargs):
+        if isinstance(expr, Indexed):                     # Indexed carries its own _sympystr: keep the reference's form
+            return str(expr)
+        return super()._print(expr, **kwargs)
+
+
+def _ctext(expr):
+    return _CText().doprint(expr) if isinstance(expr, sympy.Basic) else str(expr)
+
+
+class StatementLowering:
+    """Analysis + HIP source + JIT build + launch of one builder state."""
+
+    def __init__(self, kernel, function_name="time_step"):
+        k = self.k = kernel
+        self.name = function_name
+        # the reference-compatible printer, for its range rule, its index flattening and its expression text only: its
+        # constructor renders the whole function (and, like the reference, needs an input constant for the signature)
+        self.cpp = CPPPrinter.__new__(CPPPrinter)
+        CodePrinter.__init__(self.cpp, kernel, function_name)
+        if not k.items:
+            raise LoweringRefused("no item declared: nothing to pass to the kernel")
+        if k.parents:
+            raise LoweringRefused("items / constants with a parent object (%s) live inside a host C++ object the device cannot see"
+                                  % ", ".join(sorted(k.parents)))
+        full = k.patch_size + 2 * k.halo_size
+        # arrays: name -> (doubles, leap, extent per axis), sizes as the reference allocates them (`CPPPrinter.py:62-76`)
+        self.arrays = {}
+        for name, it in k.all_items.items():
+            if not isinstance(it, sympy.tensor.indexed.IndexedBase):
+                continue
+            leap = {0: 1, 1: k.n_real, 2: k.n_real + k.n_aux}[k.item_struct[name]]
+            size = k.patch_size if (len(k.items) > 1 and name == k.items[1]) else full       # flattening rule of the reference
+            self.arrays[name] = (k.n_patches * size ** k.dim * leap, leap, size)
+        self.primary = k.items[0]
+        self.consts = list(k.inputs)
+        self.statements = []
+        dconst = {}
+        for n, (lhs, rhs, direction, span) in enumerate(zip(k.LHS, k.RHS, k.directions, k.struct_inclusion)):
+            if str(lhs) in k.directional_consts:
+                dconst[str(lhs)] = rhs
+                continue
+            self.statements.append(self._analyse(n, lhs, rhs, direction, span, dict(dconst)))
+        if not self.statements:
+            raise LoweringRefused("the statement list is empty")
+
+    # -- analysis ------------------------------------------------------------------------------------------
+    def _analyse(self, n, lhs, rhs, direction, span, dconst):
+        k = self.k
+        where = "statement %d (`%s = %s`)" % (n, lhs, rhs)
+        for e in (lhs, rhs):
+            if isinstance(e, sympy.Basic):
+                calls = [a for a in e.atoms(AppliedUndef)] + [a for a in e.atoms(sympy.Function) if type(a).__name__ in k.functions]
+                if calls or type(e).__name__ in k.functions:
+                    raise LoweringRefused("%s calls the opaque function `%s`: the reference resolves it to host C++ at link time; use a "
+                                          "recognised scheme with pde= / SymPy bodies" % (where, type((calls or [e])[0]).__name__))
+        if not isinstance(lhs, Indexed):
+            raise LoweringRefused("%s: the left-hand side is not an array element" % where)
+        if rhs is None or (isinstance(rhs, str) and rhs == ""):
+            raise LoweringRefused("%s has no right-hand side" % where)
+        rng = self.cpp._ranges([lhs, rhs], direction, span)
+        names = [str(i) for i in k.indexes]
+        bounds = {nm: (lo, hi - 1) for nm, (lo, hi) in zip(names, rng)}
+        var_loop = rng[-1][1] > 1
+        # bounds of every access, dependence of the written array
+        accesses = [lhs] + (sorted(rhs.atoms(Indexed), key=str) if isinstance(rhs, sympy.Basic) else [])
+        for a in accesses:
+            base = str(a.base)
+            if base not in self.arrays:
+                raise LoweringRefused("%s indexes `%s`, which is not a declared item" % (where, base))
+            total, leap, size = self.arrays[base]
+            strides = [leap * size ** (k.dim - m) for m in range(k.dim + 1)]           # patch, axes...
+            lo = hi = 0
+            for m, ix in enumerate(a.indices):
+                syms = [s for s in ix.free_symbols]
+                if len(syms) > 1 or any(str(s) not in bounds for s in syms):
+                    raise LoweringRefused("%s: index `%s` of `%s` is not a loop index plus an offset" % (where, ix, base))
+                if str(ix) == "var" or (syms and str(syms[0]) == "var"):
+                    vlo, vhi = (bounds["var"] if var_loop else (0, 0))
+                    lo, hi = lo + vlo, hi + vhi
+                    continue
+                stride = strides[m] if m < len(strides) else 1
+                if syms:
+                    s0 = syms[0]
+                    coeff = ix.coeff(s0)
+                    if coeff != 1:
+                        raise LoweringRefused("%s: index `%s` of `%s` is not a loop index plus an offset" % (where, ix, base))
+                    b = bounds[str(s0)]
+                    off = int(ix - s0)
+                    lo, hi = lo + stride * (b[0] + off), hi + stride * (b[1] + off)
+                else:
+                    lo, hi = lo + stride * int(ix), hi + stride * int(ix)
+            if lo < 0 or hi >= total:
+                raise LoweringRefused("%s: `%s` reaches flat index %d .. %d of an array of %d doubles over the loop range -- out of "
+                                      "bounds (the reference's text would read or write past its heap block)" % (where, a, lo, hi, total))
+            if a is not lhs and str(a.base) == str(lhs.base) and tuple(a.indices) != tuple(lhs.indices):
+                raise LoweringRefused("%s writes `%s` and reads it at another index (`%s`): a loop-carried dependence in the reference's "
+                                      "sequential loop nest, not reproducible by a parallel launch" % (where, lhs.base, a))
+        text_l = self.cpp.Cppify(lhs)
+        text_r = self.cpp.Cppify(_ctext(rhs))
+        if not var_loop:
+            text_l, text_r = text_l.replace(" + var", ""), text_r.replace(" + var", "")
+        if "**" in text_r or re.search(r"(?<![\w.])\d+/\d+(?![\w.])", text_r):
+            raise LoweringRefused("%s prints as `%s`: not the same arithmetic in C++ (a power or an integer quotient)" % (where, text_r))
+        free = set()
+        for e in (lhs, rhs):
+            if isinstance(e, sympy.Basic):
+                free |= {str(s) for s in e.free_symbols if isinstance(s, Symbol)}
+        unknown = free - set(names) - set(self.consts) - set(dconst) - {"dim", "patch_size", "halo_size", "n_real", "n_aux"}
+        unknown = {u for u in unknown if u not in self.arrays}
+        if unknown:
+            raise LoweringRefused("%s uses %s, which is neither an input constant, a directional constant nor a builder constant"
+                                  % (where, sorted(unknown)))
+        return {"n": n, "lhs": text_l, "rhs": text_r, "ranges": rng, "var_loop": var_loop,
+                "dconst": {nm: v for nm, v in dconst.items() if nm in free}, "writes": str(lhs.base)}
+
+    # -- code ----------------------------------------------------------------------------------------------
+    def array_order(self):
+        """Kernel-argument order of the arrays: the primary (caller-owned) first, then the temporaries by name."""
+        return [self.primary] + sorted(a for a in self.arrays if a != self.primary)
+
+    def source(self):
+        k = self.k
+        names = [str(i) for i in k.indexes]
+        arrs = self.array_order()
+        params = ", ".join(["double* %s" % a for a in arrs] + ["double %s" % c for c in self.consts])
+        out = ["// Generated by exahype_amd.printers.lowering for `%s`: one kernel per statement of the builder state, the reference's loop"
+               % self.name,
+               "// ranges, AoS strides and expression text (exahype/printers/CPPPrinter.py:84-137); gfx950, -ffp-contract=off.",
+               "#include <hip/hip_runtime.h>", "#include <cmath>", ""]
+        lits = "".join("    const %s\n" % lit for lit in k.literals)
+        for s in self.statements:
+            rng = s["ranges"]
+            ext = [hi - lo for lo, hi in rng]
+            if not s["var_loop"]:
+                ext[-1] = 1
+            total = 1
+            for e in ext:
+                total *= e
+            body = ["__global__ void __launch_bounds__(256) stmt_%d(%s) {" % (s["n"], params),
+                    "    const long t_ = (long)blockIdx.x * 256 + threadIdx.x;",
+                    "    if (t_ >= %dL) return;" % total, "    long r_ = t_;"]
+            for nm, (lo, hi), e in reversed(list(zip(names, rng, ext))):      # innermost (var) fastest
+                if nm == "var" and not s["var_loop"]:
+                    continue
+                body.append("    const int %s = %d + (int)(r_ %% %d); r_ /= %d;" % (nm, lo, e, e))
+            if lits:
+                body.append(lits.rstrip("\n"))
+            for nm, v in s["dconst"].items():
+                body.append("    const double %s = %s;" % (nm, v))
+            body.append("    %s = %s;" % (s["lhs"], s["rhs"]))
+            body.append("}")
+            out += body + [""]
+            s["total"] = total
+        out.append('extern "C" int exa_generated_%s(double** arrays_, const double* consts_, void* stream_) {' % self.name)
+        out.append("    hipStream_t s_ = static_cast<hipStream_t>(stream_);")
+        call = ", ".join(["arrays_[%d]" % i for i in range(len(arrs))] + ["consts_[%d]" % i for i in range(len(self.consts))])
+        for s in self.statements:
+            out.append("    hipLaunchKernelGGL(stmt_%d, dim3(%d), dim3(256), 0, s_, %s);" % (s["n"], (s["total"] + 255) // 256, call))
+        out += ["    return hipGetLastError() == hipSuccess ? 0 : -1;", "}", ""]
+        return "\n".join(out)
+
+    def key(self):
+        return hashlib.sha256(self.source().encode()).hexdigest()[:16]
+
+    def build(self, force=False):
+        """hipcc (gfx950, no FMA contraction: the reference's text evaluates every product and sum separately) -> side library."""
+        from .. import build as _build
+        d = os.path.join(GEN_DIR, "gen_" + self.key())
+        so = os.path.join(d, "libexahype_generated.so")
+        if os.path.exists(so) and not force:
+            return so
+        os.makedirs(d, exist_ok=True)
+        src = os.path.join(d, "generated.hip")
+        with open(src, "w") as f:
+            f.write(self.source())
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        r = subprocess.run([hipcc, "-O3", "-fPIC", "-shared", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-ffp-contract=off",
+                            "-Wno-unused-variable", "-Wno-unused-value", src, "-o", so], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for the generated kernels:\n%s" % r.stderr[-3000:])
+        return so
+
+    # -- execution -----------------------------------------------------------------------------------------
+    def bind(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("the generated kernels need a GPU (there is no CPU path)")
+        self._lib = C.CDLL(self.build())
+        self._fn = getattr(self._lib, "exa_generated_%s" % self.name)
+        self._fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.c_void_p]
+        self._fn.restype = C.c_int
+        self._dev = torch.device("cuda", device)
+        # temporaries: allocated once per bound kernel (the reference allocates and frees them inside every call; their
+        # content before a statement writes them is unspecified there -- heap garbage -- and zero here)
+        self._tmp = {a: torch.zeros(self.arrays[a][0], dtype=torch.float64, device=self._dev) for a in self.array_order()[1:]}
+        return self
+
+    def run(self, Q, *consts):
+        """`time_step(Q, consts...)`: Q = the primary item, a numpy array (staged through the device, updated in place) or a CUDA
+        tensor (resident); consts in the order of the builder's `const()` inputs."""
+        import numpy as np
+        import torch
+        if getattr(self, "_fn", None) is None:
+            self.bind()
+        if len(consts) != len(self.consts):
+            raise TypeError("%s takes %d constant(s) %s, got %d" % (self.name, len(self.consts), self.consts, len(consts)))
+        need = self.arrays[self.primary][0]
+        host = None
+        if isinstance(Q, np.ndarray):
+            if Q.dtype != np.float64 or Q.size != need or not Q.flags.c_contiguous:
+                raise ValueError("`%s` must be a contiguous float64 array of %d doubles" % (self.primary, need))
+            host, q = Q, torch.as_tensor(Q.reshape(-1), device=self._dev)
+        else:
+            q = Q
+            if not (q.is_cuda and q.dtype == torch.float64 and q.numel() == need and q.is_contiguous()):
+                raise ValueError("`%s` must be a contiguous float64 CUDA tensor of %d doubles" % (self.primary, need))
+        ptrs = (C.c_void_p * len(self.arrays))(*([q.data_ptr()] + [self._tmp[a].data_ptr() for a in self.array_order()[1:]]))
+        cs = (C.c_double * max(1, len(consts)))(*[float(c) for c in consts])
+        stream = torch.cuda.current_stream(self._dev).cuda_stream
+        if self._fn(ptrs, cs, C.c_void_p(stream)) != 0:
+            raise RuntimeError("launch of the generated kernels failed")
+        if host is not None:
+            host.reshape(-1)[:] = q.cpu().numpy()
+        return Q
