@@ -64,6 +64,30 @@ def test_limited_step_vs_oracle(dim, N, nc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim,N,nc", [(3, 8, (2, 1, 2)), (2, 4, (3, 2)), (3, 3, (2, 2, 2))])
+def test_all_variables_kernels_equal_the_per_variable_kernels(dim, N, nc, monkeypatch):
+    """Five-variable systems take the all-variables projection / reconstruction kernels (AoS runs, one pass over the patch);
+    EXA_LIM_PER_VARIABLE=1 sends them through the per-variable kernels every other variable count uses.  Same summation
+    order: the limited step must come out bit for bit the same."""
+    from exahype_amd import solvers as exa
+    u = euler_dg_state(tuple(nc) + (N,) * dim, seed=77)
+    dx = [1.0 / nc[0]] * dim
+    dt = 0.02 * dx[0] / (2 * N - 1)
+    mask = np.random.default_rng(3).random(nc) < 0.5
+    mask.flat[0] = True
+    res = []
+    for per_variable in ("0", "1"):
+        monkeypatch.setenv("EXA_LIM_PER_VARIABLE", per_variable)
+        s = exa.AderDgSolver(dim, N, nc, dx=dx)
+        lim = exa.SubcellLimiter(s)
+        s.upload(u)
+        for _ in range(2):
+            lim.step(dt, mask)
+        res.append(s.download())
+    assert np.array_equal(res[0], res[1])
+
+
+@pytest.mark.gpu
 def test_limiter_capacity_and_device_resident_mask():
     """The troubled count never reaches the host inside step(): the cell list is compacted on the device into `capacity`
     slots.  A CUDA mask gives the same result as a numpy mask; more troubled cells than capacity is reported by check()."""
