@@ -439,6 +439,17 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                 if (mine) {
                     double s[N][NV];
                     pencil_sums<D, N, PDE>(qw, ops_here<N>(ops_raw)->DEO, idx[D], s);
+                    if constexpr (pde_has_source<PDE>::value) {                 // q_t + div F = S(q): the x pencils carry -S(q) of their nodes
+                        if constexpr (D == 0) {
+#pragma unroll
+                            for (int i = 0; i < N; i++) {
+                                double Sq[NV];
+                                PDE::source(qw[i], Sq);
+#pragma unroll
+                                for (int v = 0; v < NV; v++) s[i][v] -= Sq[v];
+                            }
+                        }
+                    }
                     {
                     if constexpr (WIDE) {
 #pragma unroll
@@ -589,6 +600,17 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                             s[i][v] = M[i][v] + P[i][v];
                             s[N - 1 - i][v] = M[i][v] - P[i][v];
                         }
+                }
+                if constexpr (pde_has_source<PDE>::value) {                     // q_t + div F = S(q): the x pencils carry -S(q) of their nodes
+                    if constexpr (D == 0) {
+#pragma unroll
+                        for (int i = 0; i < N; i++) {
+                            double Sq[NV];
+                            PDE::source(qw[i], Sq);
+#pragma unroll
+                            for (int v = 0; v < NV; v++) s[i][v] -= Sq[v];
+                        }
+                    }
                 }
                 if constexpr (D > 0 && WIDE) {
 #pragma unroll
@@ -792,6 +814,11 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
             constexpr int D = decltype(dc)::value;
             if (grp == D && bt < TD) {
                 double qb[NV], Fb[NV];
+                [[maybe_unused]] double Sb[NV];
+                if constexpr (pde_has_source<PDE>::value) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++) Sb[v] = 0.0;
+                }
                 // all variables of u at this node: for the single-stage case, and (group 0) for the B slab the final sum reads;
                 // requested first, used last (an L2 hit: the cell was read at its start)
                 double ur[NV];
@@ -822,6 +849,14 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 #pragma unroll
                             for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[v];
                         }
+                        if constexpr (pde_has_source<PDE>::value) {          // time average of the source
+                            if constexpr (D == 0) {
+                                double Sq[NV];
+                                PDE::source(q, Sq);
+#pragma unroll
+                                for (int v = 0; v < NV; v++) Sb[v] += wm[l] * Sq[v];
+                            }
+                        }
                         PDE::template flux<D>(q, a, F);
 #pragma unroll
                         for (int v = 0; v < NV; v++) Fb[v] += wm[l] * F[v];
@@ -832,13 +867,19 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 #pragma unroll
                     for (int v = 0; v < NV; v++) qb[v] = ur[v];
                     PDE::template flux<D>(ur, a, Fb);
+                    if constexpr (pde_has_source<PDE>::value) {
+                        if constexpr (D == 0) PDE::source(ur, Sb);
+                    }
                 }
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     lds[off + ASZ + (v * NTS + 1 + D) * SL] = Fb[v];
                     if constexpr (D == 0) {
                         lds[off + ASZ + (v * NTS + 0) * SL] = qb[v];
-                        lds[off + 2 * ASZ + (v * NTS + 0) * SL] = ur[v];   // same (cell, node) as the update role of this lane
+                        // same (cell, node) as the update role of this lane; with a source: u + dt * (time-averaged source), what the
+                        // final sum adds the volume terms to
+                        if constexpr (pde_has_source<PDE>::value) lds[off + 2 * ASZ + (v * NTS + 0) * SL] = ur[v] + dt * Sb[v];
+                        else lds[off + 2 * ASZ + (v * NTS + 0) * SL] = ur[v];
                     }
                 }
             }
@@ -1019,9 +1060,12 @@ dg_stage_a_single_kernel(const double* __restrict__ u_in, double* __restrict__ u
             const long cell = cell_id[c];
             const int off = c * CS + G::node_off(n);
             if (cell >= 0) {
+                [[maybe_unused]] double Sq[NV];
+                if constexpr (pde_has_source<PDE>::value) PDE::source(ur[k], Sq);     // single stage: + dt S(u)
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     double us = ur[k][v];
+                    if constexpr (pde_has_source<PDE>::value) us += dt * Sq[v];
 #pragma unroll
                     for (int d = 0; d < DIM; d++) us += lds[off + ((1 + d) * NV + v) * SL];
                     u_out[(cell * NN + n) * NV + v] = us;

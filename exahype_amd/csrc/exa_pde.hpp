@@ -22,9 +22,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace exa {
 
 constexpr double GAMMA = 1.4;
+
+// Optional member of a PDE struct: `static constexpr bool HAS_SOURCE = true` with `source(q, S)` = the algebraic source S(q)[NV] of
+// q_t + div F(q) = S(q) (the hook the reference's harness declares next to flux and maxEigenvalue, `Unit test/correctness_test.cpp:16-23`;
+// SURVEY.md 8(f)-2).  The built-in term sets have none; pde_codegen.SympyPDE(source=...) generates one.
+template <class P, class = void> struct pde_has_source : std::false_type {};
+template <class P> struct pde_has_source<P, std::void_t<decltype(P::HAS_SOURCE)>> : std::bool_constant<P::HAS_SOURCE> {};
 
 // 1/x from v_rcp_f64 + EXA_RCP_NR Newton steps.  Measured on MI355X against the IEEE quotient
 // (scripts/rcp_accuracy.hip, 4M values): bare v_rcp_f64 2.6e8 ulp, one step <= 11 ulp (2.5e-15 relative), two

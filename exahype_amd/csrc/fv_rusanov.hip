@@ -214,6 +214,15 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             }
 #pragma unroll
             for (int v = 0; v < MAXV; v++) nv[k][v] = qc[v] - dt_over_h * acc[v];
+            if constexpr (pde_has_source<PDE>::value) {              // q_t + div F = S(q): + dt S(q) of the volume itself
+                double Sq[MAXV];
+#pragma unroll
+                for (int v = 0; v < MAXV; v++) Sq[v] = 0.0;
+                PDE::source(qc, Sq);
+#pragma unroll
+                for (int v = 0; v < MAXV; v++)
+                    if (v < m) nv[k][v] += dt * Sq[v];
+            }
         }
     }
     // every read of this patch is done (loads feed the values above) before any write
@@ -544,6 +553,15 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
                     }
 #pragma unroll
                     for (int v = 0; v < MAXV; v++) out[v] = qc[v] - dt_over_h * acc[v];
+                    if constexpr (pde_has_source<PDE>::value) {
+                        double Sq[MAXV];
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++) Sq[v] = 0.0;
+                        PDE::source(qc, Sq);
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++)
+                            if (v < m) out[v] += dt * Sq[v];
+                    }
                 }
             }
             // shift the column

@@ -42,13 +42,23 @@ class _DevicePrinter(C99CodePrinter):
 
 
 class SympyPDE:
-    def __init__(self, n_vars, flux, max_eigenvalue, max_dim=3, name="user"):
+    def __init__(self, n_vars, flux, max_eigenvalue, max_dim=3, name="user", source=None):
+        """flux(q, d) -> n_vars expressions, max_eigenvalue(q, d) -> one, in the state symbols q; d = 0-based normal.
+        source(q) -> n_vars expressions (optional): the algebraic source S(q) of q_t + div F(q) = S(q) -- the hook the
+        reference's harness declares beside flux and maxEigenvalue (`Unit test/correctness_test.cpp:16-23`).  It enters the
+        ADER-DG predictor, the time-averaged volume term and the corrected FV update; not supported by the level-streamed
+        p = 6, 7 kernel, and the faithful FV mode (the reference's statement list) has no source by construction."""
         if not 1 <= n_vars <= 8:
             raise ValueError("n_vars must be 1..8")
         self.n_vars, self.max_dim, self.name = n_vars, max_dim, name
         self.q = self.state(n_vars)
         self.flux_exprs = []
         self.eig_exprs = []
+        self.source_exprs = None
+        if source is not None:
+            self.source_exprs = [sympy.sympify(e) for e in source(self.q)]
+            if len(self.source_exprs) != n_vars:
+                raise ValueError("source(q) must return %d expressions" % n_vars)
         for d in range(max_dim):
             f = [sympy.sympify(e) for e in flux(self.q, d)]
             if len(f) != n_vars:
@@ -77,6 +87,11 @@ class SympyPDE:
         for d in range(self.max_dim):
             flux_cases.append("        case %d: {\n%s\n        } break;" % (d, self._block(self.flux_exprs[d], ["F[%d]" % v for v in range(n)], "            ")))
             eig_cases.append("        case %d: {\n%s\n            return lam;\n        }" % (d, self._block([self.eig_exprs[d]], ["const double lam"], "            ")))
+        src_member = ""
+        if self.source_exprs is not None:
+            src_member = ("    static constexpr bool HAS_SOURCE = true;\n"
+                          "    __device__ static inline void source(const double* q, double* S) {\n%s\n    }\n"
+                          % self._block(self.source_exprs, ["S[%d]" % v for v in range(n)], "        "))
         return """// generated by exahype_amd/pde_codegen.py from SymPy expressions -- user PDE term set "%s"
 #pragma once
 #include <hip/hip_runtime.h>
@@ -108,9 +123,9 @@ struct UserPDE {
         return 0.0;
     }
     __device__ static inline double maxeig_fast(const double* q, int d) { return maxeig(q, d); }
-};
+%s};
 }  // namespace exa
-""" % (self.name, n, n, self.max_dim, "\n".join(flux_cases), "\n".join(eig_cases))
+""" % (self.name, n, n, self.max_dim, "\n".join(flux_cases), "\n".join(eig_cases), src_member)
 
     def key(self):
         h = hashlib.sha256(self.source().encode())

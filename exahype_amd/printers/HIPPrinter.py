@@ -223,8 +223,11 @@ class HIPPrinter(CodePrinter):
             return None
         if flux is None or eig is None:
             raise ValueError("SymPy bodies are needed for both the flux and the eigenvalue function (got one)")
+        # optional: the algebraic source term, under the name the reference's harness uses for the hook
+        # (`Unit test/correctness_test.cpp:16-23`): body(q) -> n_real expressions
+        src = next((bodies[n] for n in bodies if n.lower() in ("sourceterm", "source")), None)
         from ..pde_codegen import SympyPDE
-        return SympyPDE(k.n_real, flux=flux, max_eigenvalue=eig, max_dim=k.dim)
+        return SympyPDE(k.n_real, flux=flux, max_eigenvalue=eig, max_dim=k.dim, source=src)
 
     def compile(self):
         """Bind libexahype_hip.so (built with hipcc if missing) and create the plan.  Raises without a GPU."""

@@ -87,6 +87,8 @@ def predictor(u, dt, dx, ops, pde, n_it=None):
         S = np.zeros_like(q)
         for a in range(d):
             S += _apply(D, pde.flux(q, a), d + 1 + a) / dx[a]
+        if hasattr(pde, "source"):                 # q_t + div F = S(q): the algebraic source enters beside the flux divergence
+            S -= pde.source(q)
         R = F0.reshape(tshape) * ue - dt * w.reshape(tshape) * S
         q = _apply(iK1, R, d)
     return q
@@ -166,6 +168,8 @@ def step(u, dt, dx, ops, pde, n_it=None, stages=False):
     q = predictor(u, dt, dx, ops, pde, n_it)
     qbar, Fbar = time_averages(q, ops, pde)
     us = volume(u, Fbar, dt, dx, ops)
+    if hasattr(pde, "source"):                     # + dt * time average of the source over the predictor
+        us = us + dt * np.tensordot(ops['w'], pde.source(q), axes=([0], [d]))
     tr = traces(qbar, Fbar, ops)
     Fs = riemann(tr, pde, d)
     un = corrector(us, Fs, dt, dx, ops)
@@ -179,6 +183,8 @@ def step_single_stage(u, dt, dx, ops, pde):
     d = _dim(u)
     Fbar = [pde.flux(u, a) for a in range(d)]
     us = volume(u, Fbar, dt, dx, ops)
+    if hasattr(pde, "source"):
+        us = us + dt * pde.source(u)
     tr = traces(u, Fbar, ops)
     Fs = riemann(tr, pde, d)
     return corrector(us, Fs, dt, dx, ops)

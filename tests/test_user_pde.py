@@ -49,6 +49,15 @@ def euler_sympy():
     return SympyPDE(5, flux, eig, max_dim=3, name="euler_from_sympy")
 
 
+def reaction_advection(k=3.0, max_dim=3):
+    """Two advected species with a linear reaction chain -- a system with an algebraic source term:
+    q_t + a . grad q = S(q),  S = (-k q0, k q0 - 2 k q1)."""
+    from exahype_amd.pde_codegen import SympyPDE
+    a = (1.0, 0.5, -0.25)
+    return SympyPDE(2, flux=lambda q, d: [a[d] * q[0], a[d] * q[1]], max_eigenvalue=lambda q, d: sympy.Float(abs(a[d])),
+                    source=lambda q: [-k * q[0], k * q[0] - 2 * k * q[1]], max_dim=max_dim, name="reaction_advection")
+
+
 class NumpyPDE:
     """The same expressions, lambdified, with the interface oracle/aderdg_numpy.py expects."""
 
@@ -56,6 +65,9 @@ class NumpyPDE:
         self.m = spde.n_vars
         self._f = [sympy.lambdify(spde.q, spde.flux_exprs[d], "numpy") for d in range(spde.max_dim)]
         self._e = [sympy.lambdify(spde.q, spde.eig_exprs[d], "numpy") for d in range(spde.max_dim)]
+        if getattr(spde, "source_exprs", None) is not None:
+            s_ = sympy.lambdify(spde.q, spde.source_exprs, "numpy")
+            self.source = lambda q: np.stack([np.broadcast_to(o, q.shape[:-1]) for o in s_(*[q[..., v] for v in range(self.m)])], axis=-1)
 
     def flux(self, q, d):
         out = self._f[d](*[q[..., v] for v in range(self.m)])
@@ -203,3 +215,109 @@ def test_function_bodies_run_like_the_sympy_pde():
     b = u.copy()
     HIPPrinter(k0, scheme="aderdg", grid=grid, pde=swe()).run(b, 1e-3, dx=dx, steps=2)
     assert np.array_equal(a, b) and not np.array_equal(a, u)
+
+
+def test_source_term_reaches_the_generated_device_code():
+    p = reaction_advection()
+    src = p.source()
+    assert "HAS_SOURCE = true" in src and "static inline void source(const double* q, double* S)" in src
+    # and through the operator surface: a function named like the reference harness's hook, with a body
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import HIPPrinter
+    k = KernelBuilder(dim=2, patch_size=4, halo_size=0, n_real=2, n_aux=0, n_patches=6)
+    k.item('u')
+    k.function('flux', body=lambda q, d: [q[0], q[1]])
+    k.function('maxEigenvalue', body=lambda q, d: sympy.Integer(1))
+    k.function('sourceTerm', body=lambda q: [-3 * q[0], 3 * q[0] - 6 * q[1]])
+    hp = HIPPrinter(k, scheme="aderdg", grid=(3, 2))
+    assert "HAS_SOURCE = true" in hp.user_pde.source() and "S[1] = -6*q[1] + t_0;" in hp.user_pde.source()   # (common sub-expression 3 q0)
+    assert "HAS_SOURCE" not in swe().source()                   # term sets without a source generate none
+    with pytest.raises(ValueError):
+        from exahype_amd.pde_codegen import SympyPDE
+        SympyPDE(2, flux=lambda q, d: [q[0], q[1]], max_eigenvalue=lambda q, d: 1, source=lambda q: [q[0]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,N,nc", [(2, 4, (3, 2)), (3, 6, (2, 1, 2)), (3, 5, (2, 2, 1)), (2, 3, (2, 3))])
+def test_source_term_aderdg_vs_numpy_oracle(dim, N, nc):
+    """q_t + div F = S(q): the source enters the predictor beside the flux divergence, its time average the volume update
+    (oracle/aderdg_numpy.py).  Full predictor and single-stage scheme; both forms of the Picard loop (N = 6 / N = 5, 3)."""
+    from exahype_amd import solvers as exa
+    from oracle import aderdg_numpy as A
+    from oracle.dg_operators import operators
+    p = reaction_advection()
+    rng = np.random.default_rng(N)
+    u = 1.0 + 0.3 * rng.random(tuple(nc) + (N,) * dim + (2,))
+    dx = [1.0 / c for c in nc]
+    dt = 0.05 * min(dx) / (2 * N - 1)
+    for n_picard, ref_step in ((-1, lambda v: A.step(v, dt, dx, operators(N), NumpyPDE(p))),
+                               (0, lambda v: A.step_single_stage(v, dt, dx, operators(N), NumpyPDE(p)))):
+        s = exa.AderDgSolver(dim, N, nc, pde=p.register(), n_vars=2, dx=dx, n_picard=n_picard)
+        s.upload(u)
+        ref = u.copy()
+        for _ in range(2):
+            s.step(dt)
+            ref = ref_step(ref)
+        assert np.max(np.abs(s.download() - ref)) / np.max(np.abs(ref)) < 1e-10, n_picard
+    # the oracle WITHOUT the source is far from what the kernel produced: the term is really in the kernel
+    plain = NumpyPDE(p)
+    del plain.source
+    ref0 = u.copy()
+    for _ in range(2):
+        ref0 = A.step_single_stage(ref0, dt, dx, operators(N), plain)
+    assert np.max(np.abs(s.download() - ref0)) > 1e-6
+
+
+@pytest.mark.gpu
+def test_source_term_decay_matches_the_exact_solution():
+    """A constant state obeys the ODE q' = S(q): q0 = e^{-kt}, q1 = e^{-kt} - e^{-2kt} from (1, 0).  ADER-DG of order N integrates
+    it to ~ (k dt)^(N+1) per step."""
+    from exahype_amd import solvers as exa
+    k, N, nc = 3.0, 6, (2, 2, 2)
+    p = reaction_advection(k)
+    u = np.zeros(nc + (N,) * 3 + (2,))
+    u[..., 0] = 1.0
+    s = exa.AderDgSolver(3, N, nc, pde=p.register(), n_vars=2, dx=[0.5] * 3)
+    s.upload(u)
+    T, steps = 0.2, 8
+    for _ in range(steps):
+        s.step(T / steps)
+    got = s.download()
+    exact = np.array([np.exp(-k * T), np.exp(-k * T) - np.exp(-2 * k * T)])
+    assert np.max(np.abs(got - exact)) < 1e-9
+    assert np.max(np.abs(got - got[0, 0, 0, 0, 0, 0])) < 1e-10          # and stays constant in space (D applied to a constant is round-off)
+
+
+@pytest.mark.gpu
+def test_source_term_fv_rusanov_vs_numpy():
+    from exahype_amd import solvers as exa
+    p = reaction_advection()
+    npde = NumpyPDE(p)
+    n_patches, P, H = 4, 5, 1
+    S = P + 2 * H
+    Q = 1.0 + 0.3 * np.random.default_rng(2).random((n_patches, S, S, 2))
+    dt, h = 2e-3, 0.05
+    kern = exa.FVRusanovKernel(2, P, H, 2, 0, n_patches, pde=p.register(), mode=exa.FV_RUSANOV)
+    got = np.ascontiguousarray(Q.copy())
+    kern.time_step(got, dt, h)
+    acc = np.zeros((n_patches, P, P, 2))
+    core = (slice(None), slice(H, H + P), slice(H, H + P))
+    for d in range(2):
+        sh = lambda a, s_: np.roll(a, -s_, axis=1 + d)[core]
+        qc, qp, qm = Q[core], sh(Q, 1), sh(Q, -1)
+        lc, lp, lm = npde.maxeig(qc, d), npde.maxeig(qp, d), npde.maxeig(qm, d)
+        Fc, Fp, Fm = npde.flux(qc, d), npde.flux(qp, d), npde.flux(qm, d)
+        acc += 0.5 * (Fc + Fp) - 0.5 * np.maximum(lc, lp)[..., None] * (qp - qc)
+        acc -= 0.5 * (Fm + Fc) - 0.5 * np.maximum(lm, lc)[..., None] * (qc - qm)
+    want = Q.copy()
+    want[core] = Q[core] - dt / h * acc + dt * npde.source(Q[core])
+    assert np.max(np.abs(got - want)) < 1e-12
+
+
+@pytest.mark.gpu
+def test_source_term_is_refused_by_the_level_streamed_kernel():
+    from exahype_amd import solvers as exa
+    p = reaction_advection()
+    s = exa.AderDgSolver(3, 8, (1, 1, 1), pde=p.register(), n_vars=2)
+    with pytest.raises(RuntimeError, match="source term"):
+        s.step(1e-3)
