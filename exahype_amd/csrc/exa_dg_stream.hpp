@@ -86,7 +86,7 @@ template <int N, class PDE, int HS, int OH> struct StageAStream {
     static constexpr int QSZ = NV * LG * G::SL;               // Q, A, B
     static constexpr int AXO = 3 * QSZ;                       // flux scalars [a][slot][node]
     static constexpr int PIC_D = 3 * QSZ + NA * LG * G::SL;   // Picard phases
-    static constexpr int FIN_D = 4 * NV * G::SL;              // final phases: qbar, Fbar_x, Fbar_y, Fbar_z
+    static constexpr int FIN_D = (pde_has_source<PDE>::value ? 5 : 4) * NV * G::SL;   // final phases: qbar, Fbar_x, Fbar_y, Fbar_z (, time-averaged source)
     static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(PIC_D > FIN_D ? PIC_D : FIN_D);
     static constexpr int TH = LG * G::NF;                     // pencils per direction and step
     static constexpr int HW = ((TH + 63) / 64) * 64;          // lanes of one task part of a direction group (wave-aligned)
@@ -338,6 +338,18 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                                     for (int v = 0; v < NV; v++) lds[D * QSZ + soff + v * LG * SL + i * ps] = s[i][v];
                                 }
                         } else {
+                            if constexpr (pde_has_source<PDE>::value) {          // q_t + div F = S(q): the x pencils carry -S(q) of their nodes
+                                static_assert(HS == 1 || !pde_has_source<PDE>::value, "source terms: whole-pencil derive tasks only");
+#pragma unroll
+                                for (int i = 0; i < HR; i++) {
+                                    double qi[NV], Sq[NV];
+#pragma unroll
+                                    for (int v = 0; v < NV; v++) qi[v] = EXA_SLD(off + v * LG * SL + i * ps);     // (Q is intact until the barrier)
+                                    PDE::source(qi, Sq);
+#pragma unroll
+                                    for (int v = 0; v < NV; v++) s[i][v] -= Sq[v];
+                                }
+                            }
                             hold = true;
                             hoff = soff;
                         }
@@ -443,6 +455,11 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
 #endif
         {
             double qb[NV], Fb[DIM][NV];
+            [[maybe_unused]] double Sbar[NV];
+            if constexpr (pde_has_source<PDE>::value) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) Sbar[v] = 0.0;
+            }
             const int o_off = opaque_v(o_off0);
             if (owner) {
                 const EXA_AS4 double* wm = ops_here<N>(ops_raw)->w;
@@ -469,6 +486,12 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
 #pragma unroll
                                 for (int v = 0; v < NV; v++) Fb[D][v] += wl * F[v];
                             });
+                            if constexpr (pde_has_source<PDE>::value) {
+                                double Sq[NV];
+                                PDE::source(acc[k], Sq);
+#pragma unroll
+                                for (int v = 0; v < NV; v++) Sbar[v] += wl * Sq[v];
+                            }
                         }
                     }
                 } else if (o_h == 0) {                           // single stage: qbar = u, Fbar = F(u)
@@ -480,6 +503,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         constexpr int D = decltype(dc)::value;
                         PDE::template flux<D>(nxt[0], a, Fb[D]);
                     });
+                    if constexpr (pde_has_source<PDE>::value) PDE::source(nxt[0], Sbar);
                 }
                 if (o_h == OH - 1) {
 #pragma unroll
@@ -487,6 +511,10 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         lds[v * SL + o_off] = qb[v];
 #pragma unroll
                         for (int d = 0; d < DIM; d++) lds[((1 + d) * NV + v) * SL + o_off] = Fb[d][v];
+                        if constexpr (pde_has_source<PDE>::value) {
+                            static_assert(OH == 1 || !pde_has_source<PDE>::value, "source terms: one owner per node only");
+                            lds[(4 * NV + v) * SL + o_off] = Sbar[v];
+                        }
                     }
                 }
             }
@@ -552,6 +580,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
             const int n = e / NV, v = e - n * NV;
             const int off = G::node_off(n);
             double us = u_in[cell * (NN * NV) + e];
+            if constexpr (pde_has_source<PDE>::value) us += dt * lds[(4 * NV + v) * SL + off];
 #pragma unroll
             for (int d = 0; d < DIM; d++) us += lds[((1 + d) * NV + v) * SL + off];
             u_out[cell * (NN * NV) + e] = us;

@@ -238,10 +238,12 @@ def test_source_term_reaches_the_generated_device_code():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,N,nc", [(2, 4, (3, 2)), (3, 6, (2, 1, 2)), (3, 5, (2, 2, 1)), (2, 3, (2, 3))])
+@pytest.mark.parametrize("dim,N,nc", [(2, 4, (3, 2)), (3, 6, (2, 1, 2)), (3, 5, (2, 2, 1)), (2, 3, (2, 3)),
+                                       (3, 8, (1, 2, 1)), (3, 7, (2, 1, 1))])         # level-streamed kernel (p = 7, 6)
 def test_source_term_aderdg_vs_numpy_oracle(dim, N, nc):
     """q_t + div F = S(q): the source enters the predictor beside the flux divergence, its time average the volume update
-    (oracle/aderdg_numpy.py).  Full predictor and single-stage scheme; both forms of the Picard loop (N = 6 / N = 5, 3)."""
+    (oracle/aderdg_numpy.py).  Full predictor and single-stage scheme; both forms of the Picard loop (N = 6 / N = 5, 3) and the
+    level-streamed kernel (N = 8, 7)."""
     from exahype_amd import solvers as exa
     from oracle import aderdg_numpy as A
     from oracle.dg_operators import operators
@@ -314,10 +316,3 @@ def test_source_term_fv_rusanov_vs_numpy():
     assert np.max(np.abs(got - want)) < 1e-12
 
 
-@pytest.mark.gpu
-def test_source_term_is_refused_by_the_level_streamed_kernel():
-    from exahype_amd import solvers as exa
-    p = reaction_advection()
-    s = exa.AderDgSolver(3, 8, (1, 1, 1), pde=p.register(), n_vars=2)
-    with pytest.raises(RuntimeError, match="source term"):
-        s.step(1e-3)
