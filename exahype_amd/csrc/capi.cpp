@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -260,6 +261,11 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
     }
     p->ops.scratch = nullptr;
     p->ops.lim = nullptr;
+    p->ops.stage_a_variant = EXA_STAGE_A_AUTO;
+    if (const char* ev = getenv("EXA_STAGE_A")) {
+        if (!strcmp(ev, "lds")) p->ops.stage_a_variant = EXA_STAGE_A_LDS;
+        else if (!strcmp(ev, "reg")) p->ops.stage_a_variant = EXA_STAGE_A_REG;
+    }
     const size_t sb = tab->scratch_bytes(N);
     if (sb > 0) {
         e = hipMalloc(&p->ops.scratch, sb);
@@ -281,6 +287,16 @@ int exa_dg_plan_destroy(exa_dg_plan* plan) {
         if (plan->ops.dev) (void)hipFree(plan->ops.dev);
         delete plan;
     }
+    return EXA_OK;
+}
+
+int exa_dg_plan_set_stage_a(exa_dg_plan* plan, int variant) {
+    if (!plan) { set_error("exa_dg_plan_set_stage_a: NULL plan"); return EXA_ERR_INVALID; }
+    if (variant != EXA_STAGE_A_AUTO && variant != EXA_STAGE_A_LDS && variant != EXA_STAGE_A_REG) {
+        set_error("exa_dg_plan_set_stage_a: variant %d (EXA_STAGE_A_AUTO|LDS|REG)", variant);
+        return EXA_ERR_INVALID;
+    }
+    plan->ops.stage_a_variant = variant;
     return EXA_OK;
 }
 

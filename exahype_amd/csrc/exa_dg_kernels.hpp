@@ -85,12 +85,21 @@ template <int K> __device__ inline void spin(double (&d)[K]) {     // values tha
 template <int N> struct DgStepOps {
     double Tdt[N * N];
     double Tsdt[N];
+    double TdtT[N * N];    // TdtT[l][l'] = Tdt[l'][l]: the column of one input level contiguous (exa_dg_reg.hpp)
 };
 template <int N> __global__ void dg_step_ops_kernel(const DgOps<N>* __restrict__ ops, DgStepOps<N>* __restrict__ so, double dt) {
     const int k = threadIdx.x;
-    if (k < N * N) so->Tdt[k] = -dt * ops->T[k];
+    if (k < N * N) {
+        so->Tdt[k] = -dt * ops->T[k];
+        so->TdtT[(k % N) * N + k / N] = -dt * ops->T[k];
+    }
     if (k < N) so->Tsdt[k] = -dt * ops->Tsum[k];
 }
+
+// Opaque copies: values derived from them cannot be hoisted out of a loop (the compiler otherwise precomputes every address
+// and predicate of every phase once per kernel and spills them).
+__device__ inline int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ inline int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 
 // Diagnostic build only (-DEXA_STAMPS): per-phase cycle stamps of wave 0, summed into a debug
 // buffer of their own (never an output element); the production kernel executes no stamp.

@@ -50,10 +50,8 @@
 
 namespace exa {
 
-// Opaque copies: values derived from them cannot be hoisted out of the step loop (the compiler otherwise
-// precomputes every address and predicate of every phase once per kernel and spills them -- 324 VGPRs).
-__device__ inline int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
-__device__ inline int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+// (opaque_v / opaque_s, exa_dg_kernels.hpp: values derived from them cannot be hoisted out of the step loop -- the compiler otherwise
+// precomputes every address and predicate of every phase once per kernel and spills them, 324 VGPRs)
 
 template <int N> struct StreamGeo {
     static constexpr int NN = N * N * N, NF = N * N;

@@ -160,6 +160,25 @@ struct Euler {
         F[4] = coeff * (q[4] + a[1]);
         F[D + 1] += a[1] * sc;
     }
+    // Normal chosen per LANE (exa_dg_reg.hpp: the lanes of a wave hold pencils of different directions): per-lane masks psc[k] =
+    // scale for the lane's own direction, 0 for the others, pick the normal momentum and place the pressure -- straight-line code,
+    // no select (a `d == 0 ? q[1] : ...` chain is turned into a run-time-indexed stack array, i.e. scratch traffic).
+    struct Dir {
+        double psc[3];
+    };
+    __device__ static inline void dir_init(Dir& c, int d, double sc) {
+        c.psc[0] = d == 0 ? sc : 0.0;
+        c.psc[1] = d == 1 ? sc : 0.0;
+        c.psc[2] = d == 2 ? sc : 0.0;
+    }
+    __device__ static inline void flux_scaled_dir(const double* q, const double* a, const Dir& c, double* F) {
+        const double coeff = a[0] * fma(q[3], c.psc[2], fma(q[2], c.psc[1], q[1] * c.psc[0]));
+        F[0] = coeff * q[0];
+        F[1] = fma(a[1], c.psc[0], coeff * q[1]);
+        F[2] = fma(a[1], c.psc[1], coeff * q[2]);
+        F[3] = fma(a[1], c.psc[2], coeff * q[3]);
+        F[4] = coeff * (q[4] + a[1]);
+    }
     __device__ static inline void flux_rt(const double* q, int d, double* F) {
         double a[2];
         aux(q, a);
@@ -226,6 +245,12 @@ template <int NVARS> struct Advection {
     template <int D> __device__ static inline void flux_scaled(const double* q, const double*, double sc, double* F) {
 #pragma unroll
         for (int v = 0; v < NV; v++) F[v] = (vel(D) * sc) * q[v];
+    }
+    struct Dir { double c; };
+    __device__ static inline void dir_init(Dir& c, int d, double sc) { c.c = vel(d) * sc; }
+    __device__ static inline void flux_scaled_dir(const double* q, const double*, const Dir& c, double* F) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) F[v] = c.c * q[v];
     }
     __device__ static inline void flux_rt(const double* q, int d, double* F) {
 #pragma unroll

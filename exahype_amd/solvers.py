@@ -237,8 +237,10 @@ class AderDgSolver:
     RCCL on a second stream while the interior cells run stage A, stage B follows.
     """
 
+    STAGE_A = {"auto": 0, "lds": 1, "reg": 2}      # include/exahype_hip.h EXA_STAGE_A_*
+
     def __init__(self, dim, N, ncells, pde=PDE_EULER, n_vars=5, n_picard=-1, dx=None, device=0, part=None,
-                 backend_is_gloo=False, fused_single_stage=True):
+                 backend_is_gloo=False, fused_single_stage=True, stage_a="auto"):
         torch = _torch()
         self.lib = _lib.load()
         self.dim, self.N, self.nv, self.pde = dim, N, n_vars, pde
@@ -249,6 +251,8 @@ class AderDgSolver:
         h = C.c_void_p()
         check(self.lib.exa_dg_plan_create(device, dim, N, n_vars, pde, n_picard, larr(self.nc), C.byref(h)))
         self._plan = h
+        if stage_a != "auto":
+            check(self.lib.exa_dg_plan_set_stage_a(h, self.STAGE_A[stage_a]))
         self.dx = [float(x) for x in (dx if dx is not None else [1.0 / c for c in self.nc])]
         self.nf = N ** (dim - 1)
         self.ts = 2 * n_vars * self.nf

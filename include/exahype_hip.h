@@ -102,6 +102,15 @@ int exa_fv_time_step_device_masked(exa_fv_plan* plan, double* Q_dev, const long*
 int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_picard, const long* ncells,
                        exa_dg_plan** plan);
 int exa_dg_plan_destroy(exa_dg_plan* plan);
+/* Which stage-A kernel the plan launches where more than one is built for its (dim, N) -- today 3-D, N = 6:
+ * EXA_STAGE_A_AUTO the library's choice (the faster one as measured on MI355X; the environment variable
+ * EXA_STAGE_A=lds|reg, read when the plan is created, overrides it), EXA_STAGE_A_LDS the LDS-resident space-time
+ * image (one workgroup per CU), EXA_STAGE_A_REG the register-resident iterate (two workgroups per CU).  Same scheme,
+ * results equal to rounding.  Other (dim, N) ignore the setting. */
+#define EXA_STAGE_A_AUTO 0
+#define EXA_STAGE_A_LDS 1
+#define EXA_STAGE_A_REG 2
+int exa_dg_plan_set_stage_a(exa_dg_plan* plan, int variant);
 long exa_dg_dof_count(const exa_dg_plan* plan);    /* doubles in u:      ncells * N^dim * n_vars */
 long exa_dg_trace_count(const exa_dg_plan* plan);  /* doubles in traces: dim*2*ncells*2*n_vars*N^(dim-1) */
 long exa_dg_face_count(const exa_dg_plan* plan, int d); /* doubles in one ghost/pack buffer for direction d */
