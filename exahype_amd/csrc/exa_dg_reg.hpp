@@ -55,6 +55,10 @@ template <class PDE> struct DirFlux<PDE, false> {
     }
 };
 
+#ifndef EXA_REG_PRIO
+#define EXA_REG_PRIO 1
+#endif
+
 template <int N> struct RegGeo {
     static constexpr int NN = N * N * N, NF = N * N;
     static constexpr int PY = N, PX = N * N;                          // node stride 1, unpadded rows and planes
@@ -66,171 +70,258 @@ template <int N> struct RegGeo {
     }
 };
 
-template <int N, class PDE> struct StageAReg {
+// CPW = cells a workgroup has in flight: 1 -> 256 threads, two workgroups per CU, each on its own; 2 -> 512 threads, one workgroup per
+// CU whose two halves run the SAME program one barrier apart, so that one half's derive phase (arithmetic) always runs beside the
+// other half's fold / load / closing phase (LDS traffic) -- the anti-phase two independent workgroups only reach by chance.
+template <int N, class PDE, int CPW = 1> struct StageAReg {
     using G = RegGeo<N>;
     static constexpr int NV = PDE::NV, NA = PDE::NAUX;
-    static constexpr int NT = 256;                                    // one wave per SIMD; two workgroups per CU
+    static constexpr int NT = 256;                                    // threads per cell in flight: one wave per SIMD
     static constexpr int LG = 2;                                      // time levels per step
     static constexpr int LS = (N + LG - 1) / LG;                      // steps per Picard iteration
     static constexpr int VS = LG * G::SL;                             // slot stride
     static constexpr int QSZ = NV * VS;                               // q (and each of the three sum arrays)
+    // FLUX_OWNER: the node owners evaluate the flux of all three directions (compile-time normals) and store F_x | F_y | F_z instead of
+    // q | flux scalars; a pencil task reads its F_d pencil and writes the sums IN PLACE over it (it is the only reader of those
+    // entries), so the image is 3 arrays, not 1 + NAUX/NV + 3.  Same arithmetic in total, 8 more LDS stores and 6 fewer loads per
+    // node and level; what it buys is BALANCE: derive and fold + load become segments of equal length, which matters where two
+    // cells are processed one segment apart (CPW == 2).
+#ifdef EXA_REG_FLUXOWN
+    static constexpr bool FLUX_OWNER = true;
+#else
+    static constexpr bool FLUX_OWNER = false;
+#endif
     static constexpr int AOFF = QSZ;                                  // flux scalars
-    static constexpr int SOFF = (NV + NA) * VS;                       // S_d at SOFF + d * QSZ
+    static constexpr int SOFF = FLUX_OWNER ? 0 : (NV + NA) * VS;      // S_d at SOFF + d * QSZ
     static constexpr int PIC_D = SOFF + 3 * QSZ;
     static constexpr int FS = G::NN;                                  // closing phases: [array][var][node], arrays qbar | Fbar_x | Fbar_y | Fbar_z (| source)
     static constexpr int FIN_D = (pde_has_source<PDE>::value ? 5 : 4) * NV * FS;
-    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(PIC_D > FIN_D ? PIC_D : FIN_D);
-    static constexpr bool FITS = G::NN <= NT && 2 * LDS_BYTES + 2048 <= 160 * 1024;
+    static constexpr int CELL_D = PIC_D > FIN_D ? PIC_D : FIN_D;      // doubles of LDS per cell in flight
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)CELL_D * CPW;
+    static constexpr bool FITS = G::NN <= NT && 2 * sizeof(double) * (size_t)CELL_D + 2048 <= 160 * 1024;
     // behind the image of dg_stage_a_kernel (StageA<3, N, PDE, CPB>::IMAGE_BYTES): lane -> packed derive task of a two-level
     // step, and of iteration 0 (one level); packed = d | level slot << 2 | pencil << 3, -1 = idle
     static constexpr int TAB_INTS = 2 * NT;
 };
 
-template <int N, class PDE>
-__global__ void __launch_bounds__(256, 2)
+template <int N, class PDE, int CPW>
+__global__ void __launch_bounds__(256 * CPW, 2)
 dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
                       long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
                       const void* __restrict__ ops_raw, const int* __restrict__ tab, const void* __restrict__ step_raw) {
     using G = RegGeo<N>;
-    using SA = StageAReg<N, PDE>;
+    using SA = StageAReg<N, PDE, CPW>;
     constexpr int NV = SA::NV, NA = SA::NA, DIM = 3;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL, PX = G::PX, PY = G::PY;
     constexpr int NT = SA::NT, LS = SA::LS, VS = SA::VS, QSZ = SA::QSZ, AOFF = SA::AOFF, SOFF = SA::SOFF, FS = SA::FS;
     constexpr int H = N / 2;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-
-    const int tid = threadIdx.x;
-    [[maybe_unused]] const int bt = tid, grp = 0;                      // (stamp builds)
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // which of the workgroup's cells in flight (wave-uniform)
+    const int tid = threadIdx.x & 255;
+    __attribute__((address_space(3))) double* lds = (__attribute__((address_space(3))) double*)lds_all + half * SA::CELL_D;
+    [[maybe_unused]] const int bt = (tid & 63) + 64 * half, grp = tid >> 6;   // (stamp builds: one column per wave of the first cell in flight)
     EXA_STAMP_INIT();
-    const bool owner = tid < NN;
-    const int o_n = owner ? tid : 0;
+    const bool node_lane = tid < NN;
+    const int o_n = node_lane ? tid : 0;
     const int pk2 = tab[tid], pk1 = tab[NT + tid];
 
     // ---- derive: one pencil task per lane, run-time direction.  s_i = sum_j D[i][j] (1/dx_d) f_d(q_j), even-odd form.
-    auto derive = [&](int pk_in, int nl) {
-        const int pk = opaque_v(pk_in);                                // (decoded here, every time: nothing of it lives across the phases)
-        const int ls = (pk >> 2) & 1;
-        if (pk >= 0 && ls < nl) {
-            const int d = pk & 3, t = pk >> 3;
-            const int a = t / N, b = t - a * N;
-            const int off = ls * SL + (d == 0 ? a * PY + b : (d == 1 ? a * PX + b : a * PX + b * PY));
-            const int ps = d == 0 ? PX : (d == 1 ? PY : 1);
-            const int so = off + SOFF + d * QSZ;                       // where the sums of this pencil go
-            const DirFlux<PDE> fx(d, d == 0 ? idx0 : (d == 1 ? idx1 : idx2));
-            const EXA_AS4 double* Em = ops_here<N>(ops_raw)->DEO;
-            double P[H > 0 ? H : 1][NV], M[H > 0 ? H : 1][NV], mid[NV], s[N][NV];
+    // Em = DgOps::DEO in SGPRs (requested before the barrier in front of the phase).  The LDS loads of node pair j + 1 are issued
+    // before the arithmetic of pair j: with two waves per SIMD nothing else hides the LDS latency of a wave.
+    constexpr int NE = H * N + H + 1;
+    struct Task {                                                      // one pencil task, decoded: first node, node stride, first sum (doubles)
+        int off, ps, so;
+        bool on;
+    };
+    auto decode = [&](int pk, Task& k, DirFlux<PDE>& fx) {
+        const int d = pk & 3, ls = (pk >> 2) & 1, t = pk >> 3;
+        const int a = t / N, b = t - a * N;
+        k.on = pk >= 0;
+        k.off = ls * SL + (d == 0 ? a * PY + b : (d == 1 ? a * PX + b : a * PX + b * PY));
+        k.ps = d == 0 ? PX : (d == 1 ? PY : 1);
+        k.so = k.off + SOFF + d * QSZ;
+        fx = DirFlux<PDE>(d, d == 0 ? idx0 : (d == 1 ? idx1 : idx2));
+    };
+    // the task of the two-level steps stays decoded in registers (30 integer instructions per step otherwise, 12 % of the phase)
+    Task tk2;
+    DirFlux<PDE> fx2(0, 0.0);
+    decode(pk2, tk2, fx2);
+    bool active_now = true;
+    // first half: every node of the pencil is requested at once; flux at the nodes; the even / odd combinations e_j = F_j + F_{N-1-j},
+    // o_j = F_j - F_{N-1-j} stay in registers
+    static_assert(N % 2 == 0, "register-resident stage A: even N (the middle node of an odd N is not coded)");
+    auto derive_a = [&](const Task& tk, const DirFlux<PDE>& fx, double (&e)[H][NV], double (&o)[H][NV]) {
+        if constexpr (SA::FLUX_OWNER) {
+            if (tk.on && active_now) {
+                const int so = tk.so, ps = tk.ps;
+                double Fn[N][NV];
 #pragma unroll
-            for (int i = 0; i < H; i++)
+                for (int j = 0; j < H; j++)
 #pragma unroll
-                for (int v = 0; v < NV; v++) P[i][v] = M[i][v] = 0.0;
+                    for (int v = 0; v < NV; v++) {
+                        Fn[j][v] = EXA_LD(so + j * ps + v * VS);
+                        Fn[N - 1 - j][v] = EXA_LD(so + (N - 1 - j) * ps + v * VS);
+                    }
 #pragma unroll
-            for (int v = 0; v < NV; v++) mid[v] = 0.0;
+                for (int j = 0; j < H; j++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        e[j][v] = Fn[j][v] + Fn[N - 1 - j][v];
+                        o[j][v] = Fn[j][v] - Fn[N - 1 - j][v];
+                    }
+            }
+        } else
+        if (tk.on && active_now) {
+            const int off = tk.off, ps = tk.ps;
+            double qn[N][NV], an[N][NA];
 #pragma unroll
             for (int j = 0; j < H; j++) {
                 const int ja = off + j * ps, jb = off + (N - 1 - j) * ps;
-                double qa[NV], aa[NA], Fa[NV], qb[NV], ab[NA], Fb[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    qa[v] = EXA_LD(ja + v * VS);
-                    qb[v] = EXA_LD(jb + v * VS);
+                    qn[j][v] = EXA_LD(ja + v * VS);
+                    qn[N - 1 - j][v] = EXA_LD(jb + v * VS);
                 }
 #pragma unroll
                 for (int k = 0; k < NA; k++) {
-                    aa[k] = EXA_LD(ja + AOFF + k * VS);
-                    ab[k] = EXA_LD(jb + AOFF + k * VS);
-                }
-                fx(qa, aa, Fa);
-                fx(qb, ab, Fb);
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
-                    Fa[v] = e;
-                    Fb[v] = o;
-                }
-#pragma unroll
-                for (int i = 0; i < H; i++) {
-                    const double ea = Em[j * N + i], eb = Em[j * N + H + i];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        P[i][v] += ea * Fa[v];
-                        M[i][v] += eb * Fb[v];
-                    }
-                }
-                if constexpr (N % 2 == 1) {
-                    const double em = Em[j * N + 2 * H];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) mid[v] += em * Fb[v];
+                    an[j][k] = EXA_LD(ja + AOFF + k * VS);
+                    an[N - 1 - j][k] = EXA_LD(jb + AOFF + k * VS);
                 }
             }
-            if constexpr (N % 2 == 1) {                                // middle node
-                const int jc = off + H * ps;
-                double qa[NV], aa[NA], Fa[NV];
 #pragma unroll
-                for (int v = 0; v < NV; v++) qa[v] = EXA_LD(jc + v * VS);
-#pragma unroll
-                for (int k = 0; k < NA; k++) aa[k] = EXA_LD(jc + AOFF + k * VS);
-                fx(qa, aa, Fa);
-#pragma unroll
-                for (int i = 0; i < H; i++) {
-                    const double ec = Em[H * N + i];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) P[i][v] += ec * Fa[v];
-                }
-#pragma unroll
-                for (int v = 0; v < NV; v++) s[H][v] = mid[v];
-            }
-#pragma unroll
-            for (int i = 0; i < H; i++)
+            for (int j = 0; j < H; j++) {
+                double Fa[NV], Fb[NV];
+                fx(qn[j], an[j], Fa);
+                fx(qn[N - 1 - j], an[N - 1 - j], Fb);
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    s[i][v] = M[i][v] + P[i][v];
-                    s[N - 1 - i][v] = M[i][v] - P[i][v];
+                    e[j][v] = Fa[v] + Fb[v];
+                    o[j][v] = Fa[v] - Fb[v];
                 }
-#pragma unroll
-            for (int i = 0; i < N; i++)
-#pragma unroll
-                for (int v = 0; v < NV; v++) EXA_ST(so + i * ps + v * VS, s[i][v]);
+            }
         }
     };
+    // second half: output-stationary by row pair (i, N-1-i), each pair stored as soon as it is complete -- its stores drain under the
+    // arithmetic of the next pair (stored all at the end, the 30 stores of each of the four waves queue up in front of the barrier)
+    auto derive_b = [&](const Task& tk, const double (&Em)[NE], const double (&e)[H][NV], const double (&o)[H][NV]) {
+        if (tk.on && active_now) {
+            const int ps = tk.ps, so = tk.so;
+#pragma unroll
+            for (int i = 0; i < H; i++) {
+                // s_i = M + P, s_{N-1-i} = M - P with M = sum_j Eo[j][i] o_j, P = sum_j Ee[j][i] e_j: the P chain starts from M (no separate add),
+                // the mirror row is 2 M - s_i (one FMA): 7 instead of 8 instructions per row pair and variable
+                double M[NV], sI[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) M[v] = Em[H + i] * o[0][v];
+#pragma unroll
+                for (int j = 1; j < H; j++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) EXA_FMA(M[v], Em[j * N + H + i], o[j][v]);
+#pragma unroll
+                for (int v = 0; v < NV; v++) sI[v] = M[v];
+#pragma unroll
+                for (int j = 0; j < H; j++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) EXA_FMA(sI[v], Em[j * N + i], e[j][v]);
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    EXA_ST(so + i * ps + v * VS, sI[v]);
+                    EXA_ST(so + (N - 1 - i) * ps + v * VS, fma(2.0, M[v], -sI[v]));
+                }
+            }
+        }
+    };
+    // (-DEXA_REG_SPLIT, CPW == 2: a barrier between the halves, i.e. three segments of similar length per step, the second cell in flight one
+    //  segment behind the first -- measured 9 % SLOWER than two segments: a barrier costs more than the better balance returns,
+    //  profiles/r03_reg_kernel.txt)
+    auto derive = [&](const Task& tk, const DirFlux<PDE>& fx, const double (&Em)[NE]) {
+        double e[H][NV], o[H][NV];
+        // the derive stream is the long one of a step: it gets the SIMD's issue slots ahead of the co-resident wave of the other cell in
+        // flight (in its fold / load / closing segment) -- 8 % of the launch (profiles/r03_reg_kernel.txt)
+        __builtin_amdgcn_s_setprio(EXA_REG_PRIO);
+        derive_a(tk, fx, e, o);
+#ifdef EXA_REG_SPLIT
+        if constexpr (CPW == 2) __syncthreads();
+#endif
+        derive_b(tk, Em, e, o);
+        __builtin_amdgcn_s_setprio(0);
+    };
 
-    // ---- persistent grid: box slot -> cell, advanced incrementally (wave-uniform integers: no 64-bit division per cell)
+    // ---- persistent grid: box slot -> cell, advanced incrementally (wave-uniform integers: no 64-bit division per cell).  Slot of this
+    // half in trip k: (blockIdx.x * CPW + half) + k * gridDim.x * CPW; every half makes the same number of trips (the barriers are the
+    // workgroup's), a half whose slot is past the end of the box idles through its last trip.
     int cx, cy, cz, sx, sy, sz;
+    long trips;
     {
-        const long b0 = blockIdx.x, g = gridDim.x;
+        const long b0 = (long)blockIdx.x * CPW + half, g = (long)gridDim.x * CPW;
         cz = (int)(b0 % box.nb[2]);
         cy = (int)((b0 / box.nb[2]) % box.nb[1]);
         cx = (int)(b0 / (box.nb[2] * box.nb[1]));
         sz = (int)(g % box.nb[2]);
         sy = (int)((g / box.nb[2]) % box.nb[1]);
         sx = (int)(g / (box.nb[2] * box.nb[1]));
+        const long first = (long)blockIdx.x * CPW;
+        trips = first < box.nbox ? (box.nbox - first + g - 1) / g : 0;
     }
     const int nb0 = (int)box.nb[0], nb1 = (int)box.nb[1], nb2 = (int)box.nb[2];
+    auto cell_of = [&](int x, int y, int z) { return ((box.lo[0] + x) * box.nc[1] + box.lo[1] + y) * box.nc[2] + box.lo[2] + z; };
+    double un[NV];                                                     // u of the NEXT cell's node, requested during this cell's closing phases
+#pragma unroll
+    for (int v = 0; v < NV; v++) un[v] = (node_lane && cx < nb0) ? u_in[(cell_of(cx, cy, cz) * NN + o_n) * NV + v] : 1.0;
+#ifndef EXA_REG_LOCKSTEP
+    if constexpr (CPW == 2) {
+        if (half == 1) __syncthreads();                                // the second half runs one barrier (= one phase) behind the first
+    }
+#endif
 
-    for (; cx < nb0;) {
-        const long cell = ((box.lo[0] + cx) * box.nc[1] + box.lo[1] + cy) * box.nc[2] + box.lo[2] + cz;
+    for (long trip = 0; trip < trips; trip++) {
+        const bool active = cx < nb0;                                  // (wave-uniform)
+        active_now = active;
+        const bool owner = node_lane && active;
+        const long cell = active ? cell_of(cx, cy, cz) : 0;
         cz += sz;
         if (cz >= nb2) { cz -= nb2; cy += 1; }
         cy += sy;
         if (cy >= nb1) { cy -= nb1; cx += 1; }
         cx += sx;
 
-        double u[NV], q[N][NV];
-#pragma unroll
-        for (int v = 0; v < NV; v++) u[v] = owner ? u_in[(cell * NN + o_n) * NV + v] : 1.0;
+        double q[N][NV];
+        double Em[NE];
+        sload<NE>(ops_here<N>(ops_raw)->DEO, Em);
 
-        // ---- Picard iteration 0: the iterate is constant in time -- one level, row sums of T
-        if (owner) {
+        // what the pencil tasks read of level slot ls at this owner's node: q and the cached flux scalars, or (FLUX_OWNER) the three fluxes
+        auto put_level = [&](int ls, const double (&qv)[NV]) {
             double a[NA];
-            PDE::aux_fast(u, a);
+            PDE::aux_fast(qv, a);
+            if constexpr (SA::FLUX_OWNER) {
+                static_for<0, DIM>([&](auto dc) {
+                    constexpr int D = decltype(dc)::value;
+                    double F[NV];
+                    PDE::template flux_scaled<D>(qv, a, D == 0 ? idx0 : (D == 1 ? idx1 : idx2), F);
 #pragma unroll
-            for (int v = 0; v < NV; v++) EXA_ST(o_n + v * VS, u[v]);
+                    for (int v = 0; v < NV; v++) EXA_ST(o_n + ls * SL + D * QSZ + v * VS, F[v]);
+                });
+            } else {
 #pragma unroll
-            for (int k = 0; k < NA; k++) EXA_ST(o_n + AOFF + k * VS, a[k]);
-        }
+                for (int v = 0; v < NV; v++) EXA_ST(o_n + ls * SL + v * VS, qv[v]);
+#pragma unroll
+                for (int k = 0; k < NA; k++) EXA_ST(o_n + ls * SL + AOFF + k * VS, a[k]);
+            }
+        };
+        // ---- Picard iteration 0: the iterate is constant in time -- one level, row sums of T
+        double ukeep[NV];                                              // u of this cell's node (iteration starts, u*): 10 VGPRs against a global re-read in front of a fold
+#pragma unroll
+        for (int v = 0; v < NV; v++) ukeep[v] = un[v];
+        if (owner) put_level(0, un);
         EXA_STAMP(0);
         __syncthreads();
         EXA_STAMP(1);
-        derive(pk1, 1);
+        {
+            Task tk1;
+            DirFlux<PDE> fx1(0, 0.0);
+            decode(opaque_v(pk1), tk1, fx1);
+            derive(tk1, fx1, Em);
+        }
         EXA_STAMP(2);
         __syncthreads();
         EXA_STAMP(3);
@@ -244,14 +335,14 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
             }
             if constexpr (pde_has_source<PDE>::value) {                // q_t + div F = S(q)
                 double Sq[NV];
-                PDE::source(u, Sq);
+                PDE::source(un, Sq);
 #pragma unroll
                 for (int v = 0; v < NV; v++) S[v] -= Sq[v];
             }
 #pragma unroll
             for (int l = 0; l < N; l++)
 #pragma unroll
-                for (int v = 0; v < NV; v++) q[l][v] = fma(Ts[l], S[v], u[v]);
+                for (int v = 0; v < NV; v++) q[l][v] = fma(Ts[l], S[v], un[v]);
         } else {
 #pragma unroll
             for (int l = 0; l < N; l++)
@@ -260,53 +351,84 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
         }
         EXA_STAMP(4);
 
-        // ---- Picard iterations 1 .. n_it - 1
+        // ---- Picard iterations 1 .. n_it - 1.  A step = [load] barrier [derive] barrier [fold]; the load of the NEXT step is issued inside the
+        // fold, between its LDS loads and its arithmetic (the levels it writes are in registers since the previous iteration, and an owner
+        // rewrites only its own node, which nobody reads between these two barriers): the 14 stores per lane drain under the fold's FMAs.
+        auto load_levels = [&](auto lc, const double (&qq)[N][NV], double (&Sq)[2][NV]) {
+            constexpr int l0 = decltype(lc)::value;
+            constexpr int NL = (l0 + 1 < N) ? 2 : 1;
+#pragma unroll
+            for (int ls = 0; ls < NL; ls++) {
+                put_level(ls, qq[l0 + ls]);
+                if constexpr (pde_has_source<PDE>::value) PDE::source(qq[l0 + ls], Sq[ls]);
+            }
+        };
+        [[maybe_unused]] double Sq[2][NV], Sqn[2][NV];                 // source terms of the levels in LDS | of the levels just loaded
+        if (n_it > 1 && owner) load_levels(std::integral_constant<int, 0>{}, q, Sq);
         for (int it = 1; it < n_it; it++) {
             double acc[N][NV];
             static_for<0, LS>([&](auto sc_) {
                 constexpr int st = decltype(sc_)::value;
                 constexpr int l0 = st * 2;
                 constexpr int NL = (l0 + 1 < N) ? 2 : 1;
-                [[maybe_unused]] double Sq[NL][NV];
-                if (owner) {
-#pragma unroll
-                    for (int ls = 0; ls < NL; ls++) {
-                        double a[NA];
-                        PDE::aux_fast(q[l0 + ls], a);
-#pragma unroll
-                        for (int v = 0; v < NV; v++) EXA_ST(o_n + ls * SL + v * VS, q[l0 + ls][v]);
-#pragma unroll
-                        for (int k = 0; k < NA; k++) EXA_ST(o_n + ls * SL + AOFF + k * VS, a[k]);
-                        if constexpr (pde_has_source<PDE>::value) PDE::source(q[l0 + ls], Sq[ls]);
-                    }
-                }
+                sload<NE>(ops_here<N>(ops_raw)->DEO, Em);
                 EXA_STAMP(5);
                 __syncthreads();
                 EXA_STAMP(6);
-                derive(pk2, NL);
+                static_assert(NL == 2, "odd N: the last step of an iteration has one level -- mask the tasks of level slot 1");
+                derive(tk2, fx2, Em);
+                // what the fold needs from memory, requested in front of the barrier: -dt T[l'][l0 + ls] (l' fastest) and, where the
+                // iteration starts its accumulators, u
+                double Tm[NL * N], uu[NV];
+#pragma unroll
+                for (int k = 0; k < NL * N; k++) Tm[k] = step_here<N>(step_raw)->TdtT[l0 * N + k];
+                if constexpr (st == 0) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++) uu[v] = ukeep[v];
+                }
                 EXA_STAMP(7);
                 __syncthreads();
                 EXA_STAMP(8);
                 if (owner) {
-                    double Tm[NL * N];                                 // -dt T[l'][l0 + ls], l' fastest
-                    sload<NL * N>(step_here<N>(step_raw)->TdtT + l0 * N, Tm);
-                    double S[NL][NV];
+                    spin(Tm);
+                    double Sx[NL][NV], Sy[NL][NV], Sz[NL][NV];         // every load first
 #pragma unroll
                     for (int ls = 0; ls < NL; ls++)
 #pragma unroll
                         for (int v = 0; v < NV; v++) {
                             const int p = o_n + ls * SL + SOFF + v * VS;
-                            const double sx_ = EXA_LD(p), sy_ = EXA_LD(p + QSZ), sz_ = EXA_LD(p + 2 * QSZ);
-                            S[ls][v] = sx_ + sy_ + sz_;
-                            if constexpr (pde_has_source<PDE>::value) S[ls][v] -= Sq[ls][v];
+                            Sx[ls][v] = EXA_LD(p);
+                            Sy[ls][v] = EXA_LD(p + QSZ);
+                            Sz[ls][v] = EXA_LD(p + 2 * QSZ);
+                        }
+                    if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q, Sqn);     // the next step's levels
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ls = 0; ls < NL; ls++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            Sx[ls][v] += Sy[ls][v] + Sz[ls][v];
+                            if constexpr (pde_has_source<PDE>::value) Sx[ls][v] -= Sq[ls][v];
                         }
 #pragma unroll
                     for (int ls = 0; ls < NL; ls++)
 #pragma unroll
                         for (int lp = 0; lp < N; lp++)
 #pragma unroll
-                            for (int v = 0; v < NV; v++)
-                                acc[lp][v] = fma(Tm[ls * N + lp], S[ls][v], (st == 0 && ls == 0) ? u[v] : acc[lp][v]);
+                            for (int v = 0; v < NV; v++) {
+                                if constexpr (st == 0) acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], ls == 0 ? uu[v] : acc[lp][v]);
+                                else acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], acc[lp][v]);
+                            }
+                    if constexpr (pde_has_source<PDE>::value) {
+#pragma unroll
+                        for (int ls = 0; ls < 2; ls++)
+#pragma unroll
+                            for (int v = 0; v < NV; v++) Sq[ls][v] = Sqn[ls][v];
+                    }
+                    // the last step of an iteration completes the new iterate: its first levels go to LDS right away
+                    if constexpr (st + 1 == LS) {
+                        if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, acc, Sq);
+                    }
                 }
                 EXA_STAMP(9);
             });
@@ -363,60 +485,77 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
         EXA_STAMP(10);
         __syncthreads();
 
-        // ---- volume integral (in place over Fbar_d) + face extrapolation: pencil tasks (d, v, t), t fastest
+        // the next cell's u for this lane (the registers of the iterate are free now); used by iteration 0 of the next cell
+#pragma unroll
+        for (int v = 0; v < NV; v++) un[v] = (node_lane && cx < nb0) ? u_in[(cell_of(cx, cy, cz) * NN + o_n) * NV + v] : 1.0;
+
+        // ---- volume integral (in place over Fbar_d) + face extrapolation: one round per direction (compile-time strides), tasks (v, t), t fastest
         {
-            constexpr int NE = H * N + H + 1;
-            for (int task = tid; task < DIM * NV * NF; task += NT) {
-                const int d = task / (NV * NF);
-                const int r = task - d * (NV * NF);
-                const int v = r / NF, t = r - v * NF;
-                const int ps = G::pstride(d);
-                const int pb = G::pbase(d, t);
-                double KE[NE], iwm[N], pl[N], pr[N];
-                sload<NE>(ops_here<N>(ops_raw)->KEO, KE);
-                sload<N>(ops_here<N>(ops_raw)->iw, iwm);
-                double qb[N], Fb[N], vol[N];
+            double KE[NE], iwm[N], pl[N], pr[N];
+            sload<NE>(ops_here<N>(ops_raw)->KEO, KE);
+            sload<N>(ops_here<N>(ops_raw)->iw, iwm);
+            sload<N>(ops_here<N>(ops_raw)->phiL, pl);
+            sload<N>(ops_here<N>(ops_raw)->phiR, pr);
+            static_assert(NV * NF <= NT, "closing phases: one round per direction");
+            const int v = tid / NF, t = tid - v * NF;
+            static_for<0, DIM>([&](auto dc) {
+                constexpr int D = decltype(dc)::value;
+                if (tid < NV * NF) {
+                    constexpr int ps = G::pstride(D);
+                    const int pb = G::pbase(D, t);
+                    double qb[N], Fb[N], vol[N];
 #pragma unroll
-                for (int j = 0; j < N; j++) {
-                    qb[j] = EXA_LD(v * FS + pb + j * ps);
-                    Fb[j] = EXA_LD(((1 + d) * NV + v) * FS + pb + j * ps);
+                    for (int j = 0; j < N; j++) {
+                        qb[j] = EXA_LD(v * FS + pb + j * ps);
+                        Fb[j] = EXA_LD(((1 + D) * NV + v) * FS + pb + j * ps);
+                    }
+                    eo_apply<N>(KE, Fb, vol);
+                    const double sc = dt * (D == 0 ? idx0 : (D == 1 ? idx1 : idx2));
+#pragma unroll
+                    for (int i = 0; i < N; i++) EXA_ST(((1 + D) * NV + v) * FS + pb + i * ps, sc * iwm[i] * vol[i]);
+                    double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        qL += pl[j] * qb[j];
+                        qR += pr[j] * qb[j];
+                        FL += pl[j] * Fb[j];
+                        FR += pr[j] * Fb[j];
+                    }
+                    if (active) {
+                        double* tl = trace + (((long)D * 2 + 0) * ncells + cell) * (2 * NV * NF);
+                        double* tr = trace + (((long)D * 2 + 1) * ncells + cell) * (2 * NV * NF);
+                        tl[(0 * NV + v) * NF + t] = qL;
+                        tl[(1 * NV + v) * NF + t] = FL;
+                        tr[(0 * NV + v) * NF + t] = qR;
+                        tr[(1 * NV + v) * NF + t] = FR;
+                    }
                 }
-                eo_apply<N>(KE, Fb, vol);
-                const double sc = dt * (d == 0 ? idx0 : (d == 1 ? idx1 : idx2));
-#pragma unroll
-                for (int i = 0; i < N; i++) EXA_ST(((1 + d) * NV + v) * FS + pb + i * ps, sc * iwm[i] * vol[i]);
-                sload<N>(ops_here<N>(ops_raw)->phiL, pl);
-                sload<N>(ops_here<N>(ops_raw)->phiR, pr);
-                double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
-#pragma unroll
-                for (int j = 0; j < N; j++) {
-                    qL += pl[j] * qb[j];
-                    qR += pr[j] * qb[j];
-                    FL += pl[j] * Fb[j];
-                    FR += pr[j] * Fb[j];
-                }
-                double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
-                double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
-                tl[(0 * NV + v) * NF + t] = qL;
-                tl[(1 * NV + v) * NF + t] = FL;
-                tr[(0 * NV + v) * NF + t] = qR;
-                tr[(1 * NV + v) * NF + t] = FR;
-            }
+            });
         }
         EXA_STAMP(11);
         __syncthreads();
 
-        // ---- u* = u + sum_d vol_d (+ dt * time-averaged source), AoS (coalesced)
-        for (int e = tid; e < NN * NV; e += NT) {
-            const int n = e / NV, v = e - n * NV;
-            double us = u_in[cell * (NN * NV) + e];
-            if constexpr (pde_has_source<PDE>::value) us += dt * EXA_LD((4 * NV + v) * FS + n);
+        // ---- u* = u + sum_d vol_d (+ dt * time-averaged source): each owner its node (u is in registers; 40 contiguous bytes per lane)
+        if (owner) {
+            double us[NV];
 #pragma unroll
-            for (int d = 0; d < DIM; d++) us += EXA_LD(((1 + d) * NV + v) * FS + n);
-            u_out[cell * (NN * NV) + e] = us;
+            for (int v2 = 0; v2 < NV; v2++) {
+                us[v2] = ukeep[v2];
+                if constexpr (pde_has_source<PDE>::value) us[v2] += dt * EXA_LD((4 * NV + v2) * FS + o_n);
+#pragma unroll
+                for (int d = 0; d < DIM; d++) us[v2] += EXA_LD(((1 + d) * NV + v2) * FS + o_n);
+            }
+            double* uo = u_out + (cell * NN + o_n) * NV;
+#pragma unroll
+            for (int v2 = 0; v2 < NV; v2++) uo[v2] = us[v2];
         }
         __syncthreads();                                               // LDS is reused by the next cell
     }
+#ifndef EXA_REG_LOCKSTEP
+    if constexpr (CPW == 2) {
+        if (half == 0) __syncthreads();                                // (the barrier the second half is behind)
+    }
+#endif
     EXA_STAMP_FLUSH();
 }
 
