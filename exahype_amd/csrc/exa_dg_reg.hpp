@@ -81,18 +81,18 @@ template <int N, class PDE, int CPW = 1> struct StageAReg {
     static constexpr int LS = (N + LG - 1) / LG;                      // steps per Picard iteration
     static constexpr int VS = LG * G::SL;                             // slot stride
     static constexpr int QSZ = NV * VS;                               // q (and each of the three sum arrays)
-    // FLUX_OWNER: the node owners evaluate the flux of all three directions (compile-time normals) and store F_x | F_y | F_z instead of
-    // q | flux scalars; a pencil task reads its F_d pencil and writes the sums IN PLACE over it (it is the only reader of those
-    // entries), so the image is 3 arrays, not 1 + NAUX/NV + 3.  Same arithmetic in total, 8 more LDS stores and 6 fewer loads per
-    // node and level; what it buys is BALANCE: derive and fold + load become segments of equal length, which matters where two
-    // cells are processed one segment apart (CPW == 2).
-#ifdef EXA_REG_FLUXOWN
-    static constexpr bool FLUX_OWNER = true;
-#else
-    static constexpr bool FLUX_OWNER = false;
+    // PAIRED (-DEXA_REG_PAIRED=1): the values of a node and level lie as 16-byte pairs (+ one 8-byte value where their number is odd), so a
+    // pencil task reads the 7 values of a node with 3 ds_read_b128 + 1 ds_read_b64 instead of 7 ds_read_b64 and writes its 5 sums with
+    // 2 + 1 stores; likewise the owners: 68 LDS instructions per step instead of 116, the same bytes.  Measured SLOWER (21.5 against
+    // 19.4 ms per 64^3 launch, profiles/r03_reg_kernel.txt): SQ_INSTS_LDS -40 %, but SQ_WAIT_INST_LDS +24 % -- a 13-cycle ds_write_b128
+    // holds the wave at the LDS queue longer than two 6-cycle stores interleaved with its arithmetic.  Off by default.
+#ifndef EXA_REG_PAIRED
+#define EXA_REG_PAIRED 0
 #endif
-    static constexpr int AOFF = QSZ;                                  // flux scalars
-    static constexpr int SOFF = FLUX_OWNER ? 0 : (NV + NA) * VS;      // S_d at SOFF + d * QSZ
+    static constexpr bool PAIRED = EXA_REG_PAIRED != 0;
+    static constexpr int NVA = NV + NA;
+    static constexpr int PS2 = 2 * VS;                                // stride of a pair array
+    static constexpr int SOFF = NVA * VS;                             // S_d at SOFF + d * QSZ
     static constexpr int PIC_D = SOFF + 3 * QSZ;
     static constexpr int FS = G::NN;                                  // closing phases: [array][var][node], arrays qbar | Fbar_x | Fbar_y | Fbar_z (| source)
     static constexpr int FIN_D = (pde_has_source<PDE>::value ? 5 : 4) * NV * FS;
@@ -104,6 +104,19 @@ template <int N, class PDE, int CPW = 1> struct StageAReg {
     static constexpr int TAB_INTS = 2 * NT;
 };
 
+// Workgroup barrier.  -DEXA_REG_LDS_BARRIER: for LDS data only -- waits for this wave's LDS operations, not for its global loads / stores
+// (the kernel hands nothing through global memory between its lanes, and __syncthreads() makes every wave wait for the acknowledgement
+// of its trace stores).
+__device__ inline void lds_barrier() {
+#ifndef EXA_REG_LDS_BARRIER          // (measured: no difference, 19.5 against 19.4 ms per 64^3 launch -- the plain barrier stays)
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
 template <int N, class PDE, int CPW>
 __global__ void __launch_bounds__(256 * CPW, 2)
 dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
@@ -113,7 +126,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
     using SA = StageAReg<N, PDE, CPW>;
     constexpr int NV = SA::NV, NA = SA::NA, DIM = 3;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL, PX = G::PX, PY = G::PY;
-    constexpr int NT = SA::NT, LS = SA::LS, VS = SA::VS, QSZ = SA::QSZ, AOFF = SA::AOFF, SOFF = SA::SOFF, FS = SA::FS;
+    constexpr int NT = SA::NT, LS = SA::LS, VS = SA::VS, QSZ = SA::QSZ, SOFF = SA::SOFF, FS = SA::FS, NVA = SA::NVA, PS2 = SA::PS2;
     constexpr int H = N / 2;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // which of the workgroup's cells in flight (wave-uniform)
@@ -125,11 +138,40 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
     const int o_n = node_lane ? tid : 0;
     const int pk2 = tab[tid], pk1 = tab[NT + tid];
 
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    // K values of one node and level (element index idx = level slot * SL + node) in the array group at `base`
+    auto ld_group = [&](int base, int idx, auto& out) {
+        constexpr int K = sizeof(out) / sizeof(double);
+        if constexpr (SA::PAIRED) {
+#pragma unroll
+            for (int u = 0; u < K / 2; u++) {
+                const d2_t t2 = *(const __attribute__((address_space(3))) d2_t*)(&lds[base + u * PS2 + 2 * idx]);
+                out[2 * u] = t2.x;
+                out[2 * u + 1] = t2.y;
+            }
+            if constexpr (K % 2 == 1) out[K - 1] = EXA_LD(base + (K / 2) * PS2 + idx);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) out[k] = EXA_LD(base + k * VS + idx);
+        }
+    };
+    auto st_group = [&](int base, int idx, const auto& in) {
+        constexpr int K = sizeof(in) / sizeof(double);
+        if constexpr (SA::PAIRED) {
+#pragma unroll
+            for (int u = 0; u < K / 2; u++) *(__attribute__((address_space(3))) d2_t*)(&lds[base + u * PS2 + 2 * idx]) = d2_t{in[2 * u], in[2 * u + 1]};
+            if constexpr (K % 2 == 1) EXA_ST(base + (K / 2) * PS2 + idx, in[K - 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) EXA_ST(base + k * VS + idx, in[k]);
+        }
+    };
+
     // ---- derive: one pencil task per lane, run-time direction.  s_i = sum_j D[i][j] (1/dx_d) f_d(q_j), even-odd form.
     // Em = DgOps::DEO in SGPRs (requested before the barrier in front of the phase).  The LDS loads of node pair j + 1 are issued
     // before the arithmetic of pair j: with two waves per SIMD nothing else hides the LDS latency of a wave.
     constexpr int NE = H * N + H + 1;
-    struct Task {                                                      // one pencil task, decoded: first node, node stride, first sum (doubles)
+    struct Task {                                                      // one pencil task, decoded: first node, node stride (elements), array group of its sums
         int off, ps, so;
         bool on;
     };
@@ -139,7 +181,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
         k.on = pk >= 0;
         k.off = ls * SL + (d == 0 ? a * PY + b : (d == 1 ? a * PX + b : a * PX + b * PY));
         k.ps = d == 0 ? PX : (d == 1 ? PY : 1);
-        k.so = k.off + SOFF + d * QSZ;
+        k.so = SOFF + d * QSZ;                                         // array group of this direction's sums
         fx = DirFlux<PDE>(d, d == 0 ? idx0 : (d == 1 ? idx1 : idx2));
     };
     // the task of the two-level steps stays decoded in registers (30 integer instructions per step otherwise, 12 % of the phase)
@@ -151,48 +193,19 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
     // o_j = F_j - F_{N-1-j} stay in registers
     static_assert(N % 2 == 0, "register-resident stage A: even N (the middle node of an odd N is not coded)");
     auto derive_a = [&](const Task& tk, const DirFlux<PDE>& fx, double (&e)[H][NV], double (&o)[H][NV]) {
-        if constexpr (SA::FLUX_OWNER) {
-            if (tk.on && active_now) {
-                const int so = tk.so, ps = tk.ps;
-                double Fn[N][NV];
-#pragma unroll
-                for (int j = 0; j < H; j++)
-#pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        Fn[j][v] = EXA_LD(so + j * ps + v * VS);
-                        Fn[N - 1 - j][v] = EXA_LD(so + (N - 1 - j) * ps + v * VS);
-                    }
-#pragma unroll
-                for (int j = 0; j < H; j++)
-#pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        e[j][v] = Fn[j][v] + Fn[N - 1 - j][v];
-                        o[j][v] = Fn[j][v] - Fn[N - 1 - j][v];
-                    }
-            }
-        } else
         if (tk.on && active_now) {
             const int off = tk.off, ps = tk.ps;
-            double qn[N][NV], an[N][NA];
+            double qa[N][NVA];                                         // q | flux scalars of the six nodes
 #pragma unroll
             for (int j = 0; j < H; j++) {
-                const int ja = off + j * ps, jb = off + (N - 1 - j) * ps;
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    qn[j][v] = EXA_LD(ja + v * VS);
-                    qn[N - 1 - j][v] = EXA_LD(jb + v * VS);
-                }
-#pragma unroll
-                for (int k = 0; k < NA; k++) {
-                    an[j][k] = EXA_LD(ja + AOFF + k * VS);
-                    an[N - 1 - j][k] = EXA_LD(jb + AOFF + k * VS);
-                }
+                ld_group(0, off + j * ps, qa[j]);
+                ld_group(0, off + (N - 1 - j) * ps, qa[N - 1 - j]);
             }
 #pragma unroll
             for (int j = 0; j < H; j++) {
                 double Fa[NV], Fb[NV];
-                fx(qn[j], an[j], Fa);
-                fx(qn[N - 1 - j], an[N - 1 - j], Fb);
+                fx(qa[j], qa[j] + NV, Fa);
+                fx(qa[N - 1 - j], qa[N - 1 - j] + NV, Fb);
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     e[j][v] = Fa[v] + Fb[v];
@@ -205,7 +218,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
     // arithmetic of the next pair (stored all at the end, the 30 stores of each of the four waves queue up in front of the barrier)
     auto derive_b = [&](const Task& tk, const double (&Em)[NE], const double (&e)[H][NV], const double (&o)[H][NV]) {
         if (tk.on && active_now) {
-            const int ps = tk.ps, so = tk.so;
+            const int off = tk.off, ps = tk.ps, so = tk.so;
 #pragma unroll
             for (int i = 0; i < H; i++) {
                 // s_i = M + P, s_{N-1-i} = M - P with M = sum_j Eo[j][i] o_j, P = sum_j Ee[j][i] e_j: the P chain starts from M (no separate add),
@@ -223,11 +236,11 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
                 for (int j = 0; j < H; j++)
 #pragma unroll
                     for (int v = 0; v < NV; v++) EXA_FMA(sI[v], Em[j * N + i], e[j][v]);
+                double sM[NV];
 #pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    EXA_ST(so + i * ps + v * VS, sI[v]);
-                    EXA_ST(so + (N - 1 - i) * ps + v * VS, fma(2.0, M[v], -sI[v]));
-                }
+                for (int v = 0; v < NV; v++) sM[v] = fma(2.0, M[v], -sI[v]);
+                st_group(so, off + i * ps, sI);
+                st_group(so, off + (N - 1 - i) * ps, sM);
             }
         }
     };
@@ -241,7 +254,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
         __builtin_amdgcn_s_setprio(EXA_REG_PRIO);
         derive_a(tk, fx, e, o);
 #ifdef EXA_REG_SPLIT
-        if constexpr (CPW == 2) __syncthreads();
+        if constexpr (CPW == 2) lds_barrier();
 #endif
         derive_b(tk, Em, e, o);
         __builtin_amdgcn_s_setprio(0);
@@ -270,7 +283,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
     for (int v = 0; v < NV; v++) un[v] = (node_lane && cx < nb0) ? u_in[(cell_of(cx, cy, cz) * NN + o_n) * NV + v] : 1.0;
 #ifndef EXA_REG_LOCKSTEP
     if constexpr (CPW == 2) {
-        if (half == 1) __syncthreads();                                // the second half runs one barrier (= one phase) behind the first
+        if (half == 1) lds_barrier();                                // the second half runs one barrier (= one phase) behind the first
     }
 #endif
 
@@ -289,24 +302,13 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
         double Em[NE];
         sload<NE>(ops_here<N>(ops_raw)->DEO, Em);
 
-        // what the pencil tasks read of level slot ls at this owner's node: q and the cached flux scalars, or (FLUX_OWNER) the three fluxes
+        // what the pencil tasks read of level slot ls at this owner's node: q and the cached flux scalars
         auto put_level = [&](int ls, const double (&qv)[NV]) {
-            double a[NA];
-            PDE::aux_fast(qv, a);
-            if constexpr (SA::FLUX_OWNER) {
-                static_for<0, DIM>([&](auto dc) {
-                    constexpr int D = decltype(dc)::value;
-                    double F[NV];
-                    PDE::template flux_scaled<D>(qv, a, D == 0 ? idx0 : (D == 1 ? idx1 : idx2), F);
+            double qa[NVA];
 #pragma unroll
-                    for (int v = 0; v < NV; v++) EXA_ST(o_n + ls * SL + D * QSZ + v * VS, F[v]);
-                });
-            } else {
-#pragma unroll
-                for (int v = 0; v < NV; v++) EXA_ST(o_n + ls * SL + v * VS, qv[v]);
-#pragma unroll
-                for (int k = 0; k < NA; k++) EXA_ST(o_n + ls * SL + AOFF + k * VS, a[k]);
-            }
+            for (int v = 0; v < NV; v++) qa[v] = qv[v];
+            PDE::aux_fast(qv, qa + NV);
+            st_group(0, o_n + ls * SL, qa);
         };
         // ---- Picard iteration 0: the iterate is constant in time -- one level, row sums of T
         double ukeep[NV];                                              // u of this cell's node (iteration starts, u*): 10 VGPRs against a global re-read in front of a fold
@@ -314,7 +316,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
         for (int v = 0; v < NV; v++) ukeep[v] = un[v];
         if (owner) put_level(0, un);
         EXA_STAMP(0);
-        __syncthreads();
+        lds_barrier();
         EXA_STAMP(1);
         {
             Task tk1;
@@ -323,15 +325,18 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
             derive(tk1, fx1, Em);
         }
         EXA_STAMP(2);
-        __syncthreads();
+        lds_barrier();
         EXA_STAMP(3);
         if (owner) {
             double S[NV], Ts[N];
             sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
+            {
+                double Sx[NV], Sy[NV], Sz[NV];
+                ld_group(SOFF, o_n, Sx);
+                ld_group(SOFF + QSZ, o_n, Sy);
+                ld_group(SOFF + 2 * QSZ, o_n, Sz);
 #pragma unroll
-            for (int v = 0; v < NV; v++) {
-                const double sx_ = EXA_LD(o_n + SOFF + v * VS), sy_ = EXA_LD(o_n + SOFF + QSZ + v * VS), sz_ = EXA_LD(o_n + SOFF + 2 * QSZ + v * VS);
-                S[v] = sx_ + sy_ + sz_;
+                for (int v = 0; v < NV; v++) S[v] = Sx[v] + (Sy[v] + Sz[v]);
             }
             if constexpr (pde_has_source<PDE>::value) {                // q_t + div F = S(q)
                 double Sq[NV];
@@ -373,7 +378,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
                 constexpr int NL = (l0 + 1 < N) ? 2 : 1;
                 sload<NE>(ops_here<N>(ops_raw)->DEO, Em);
                 EXA_STAMP(5);
-                __syncthreads();
+                lds_barrier();
                 EXA_STAMP(6);
                 static_assert(NL == 2, "odd N: the last step of an iteration has one level -- mask the tasks of level slot 1");
                 derive(tk2, fx2, Em);
@@ -387,20 +392,17 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
                     for (int v = 0; v < NV; v++) uu[v] = ukeep[v];
                 }
                 EXA_STAMP(7);
-                __syncthreads();
+                lds_barrier();
                 EXA_STAMP(8);
                 if (owner) {
                     spin(Tm);
                     double Sx[NL][NV], Sy[NL][NV], Sz[NL][NV];         // every load first
 #pragma unroll
-                    for (int ls = 0; ls < NL; ls++)
-#pragma unroll
-                        for (int v = 0; v < NV; v++) {
-                            const int p = o_n + ls * SL + SOFF + v * VS;
-                            Sx[ls][v] = EXA_LD(p);
-                            Sy[ls][v] = EXA_LD(p + QSZ);
-                            Sz[ls][v] = EXA_LD(p + 2 * QSZ);
-                        }
+                    for (int ls = 0; ls < NL; ls++) {
+                        ld_group(SOFF, o_n + ls * SL, Sx[ls]);
+                        ld_group(SOFF + QSZ, o_n + ls * SL, Sy[ls]);
+                        ld_group(SOFF + 2 * QSZ, o_n + ls * SL, Sz[ls]);
+                    }
                     if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q, Sqn);     // the next step's levels
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -439,7 +441,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
         }
 
         // ---- time averages (A.3): qbar | Fbar_x | Fbar_y | Fbar_z (| time-averaged source), node-major images of stride FS
-        __syncthreads();                                               // every fold has read its sums: the closing image reuses the LDS
+        lds_barrier();                                               // every fold has read its sums: the closing image reuses the LDS
         if (owner) {
             double wm[N];
             sload<N>(ops_here<N>(ops_raw)->w, wm);
@@ -483,7 +485,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
             }
         }
         EXA_STAMP(10);
-        __syncthreads();
+        lds_barrier();
 
         // the next cell's u for this lane (the registers of the iterate are free now); used by iteration 0 of the next cell
 #pragma unroll
@@ -533,7 +535,7 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
             });
         }
         EXA_STAMP(11);
-        __syncthreads();
+        lds_barrier();
 
         // ---- u* = u + sum_d vol_d (+ dt * time-averaged source): each owner its node (u is in registers; 40 contiguous bytes per lane)
         if (owner) {
@@ -549,11 +551,11 @@ dg_stage_a_reg_kernel(const double* __restrict__ u_in, double* __restrict__ u_ou
 #pragma unroll
             for (int v2 = 0; v2 < NV; v2++) uo[v2] = us[v2];
         }
-        __syncthreads();                                               // LDS is reused by the next cell
+        lds_barrier();                                               // LDS is reused by the next cell
     }
 #ifndef EXA_REG_LOCKSTEP
     if constexpr (CPW == 2) {
-        if (half == 0) __syncthreads();                                // (the barrier the second half is behind)
+        if (half == 0) lds_barrier();                                // (the barrier the second half is behind)
     }
 #endif
     EXA_STAMP_FLUSH();
