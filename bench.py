@@ -42,6 +42,8 @@ def spawn_ranks(n, argv):
     """Start n worker processes (one rank each) and relay rank 0's output.  The parent never initialises a GPU (no
     torch.cuda call, no HIP call): it only starts children and waits -- nothing is exec'ed over a GPU process."""
     import socket
+    from exahype_amd import build as exa_build
+    exa_build.build()                      # hipcc only, no GPU call: the ranks must not race to compile the same library
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -130,9 +132,10 @@ def cpu_threads():
     return int(os.environ.get("OMP_NUM_THREADS", max(1, min(usable, phys))))
 
 
-def cpu_baseline_dg(dim, N, n_it, seconds=12.0):
+def cpu_baseline_dg(dim, N, n_it, seconds=10.0, samples=3):
     """The oracle (oracle/exa_oracle.c, OpenMP over cells) on the host cores: the same ADER-DG step on a bounded block,
-    >= 16 cells per thread, work arrays allocated once outside the timed steps."""
+    >= 16 cells per thread, work arrays allocated once outside the timed steps.  `value` is the MEDIAN of `samples` samples of
+    `seconds` each (one sample moved by +-25 % between runs on the shared host)."""
     import numpy as np
     threads = cpu_threads()
     import oracle
@@ -153,19 +156,25 @@ def cpu_baseline_dg(dim, N, n_it, seconds=12.0):
         oracle.aderdg_run(u, dt, dx, ops, dim, N, 5, oracle.PDE_EULER, n_it, nc, 1)
         one = time.perf_counter() - t0
     chunk = int(max(1, min(500, 1.0 / max(one, 1e-6))))                                # ~1 s of steps per call, arrays allocated once per call
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.aderdg_run(u, dt, dx, ops, dim, N, 5, oracle.PDE_EULER, n_it, nc, chunk)
-        steps += chunk
-        el = time.perf_counter() - t0
-        if el >= seconds:
-            break
-    usable, phys, model = host_cpu_info()
     dof = int(np.prod(nc)) * N ** dim * 5
-    return {"value": dof * steps / el, "unit": "DoF-updates/s", "cores": threads, "kind": "port",
-            "sample": "%d steps of a %s-cell block (%d cells per thread), same p=%d Euler ADER-DG step (%d Picard iterations), "
-                      "oracle/exa_oracle.c (gcc -O3 -fopenmp), %.1f s" % (steps, "x".join(map(str, nc)), int(np.prod(nc)) // threads,
-                                                                          N - 1, n_it, el),
+    rates, total_steps, total_el = [], 0, 0.0
+    for _ in range(samples):
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            oracle.aderdg_run(u, dt, dx, ops, dim, N, 5, oracle.PDE_EULER, n_it, nc, chunk)
+            steps += chunk
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                break
+        rates.append(dof * steps / el)
+        total_steps += steps
+        total_el += el
+    usable, phys, model = host_cpu_info()
+    return {"value": sorted(rates)[len(rates) // 2], "unit": "DoF-updates/s", "cores": threads, "kind": "port",
+            "sample": "median of %d samples (%s DoF-updates/s), %d steps in all of a %s-cell block (%d cells per thread), same p=%d Euler "
+                      "ADER-DG step (%d Picard iterations), oracle/exa_oracle.c (gcc -O3 -fopenmp), %.1f s"
+                      % (samples, " / ".join("%.3g" % r for r in rates), total_steps, "x".join(map(str, nc)),
+                         int(np.prod(nc)) // threads, N - 1, n_it, total_el),
             "host": {"cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "nproc": os.cpu_count()}}
 
 
@@ -268,19 +277,22 @@ def run_cfg2(a, torch, exa, world, rank, local):
     ta = sum(e0.elapsed_time(e1) for e0, e1 in s.stage_a_events) / a.steps * 1e-3
     if world == 1:
         ach = work["flop_a"] / ta / 1e12
-        traffic, src = read_traffic("stage_a_traffic.json", cells=a.cells, order=a.order)
+        kname = s.stage_a_kernel_name()
+        traffic, src = read_traffic("stage_a_traffic.json", cells=a.cells, order=a.order, kernel=kname)
         pmc = {}
         pf = os.path.join(ROOT, "profiles", "stage_a_pmc.json")          # SQ counters of the same kernel (48^3 cells): not measured in this run
         if os.path.exists(pf) and a.order == 5:
             rec = json.load(open(pf))
-            pmc = {"valu_busy": rec["valu_issue_frac"], "lds_busy": rec["lds_array_busy_frac"], "mfma_busy": 0.0,
-                   "busy_source": "profiles/stage_a_pmc.json (rocprofv3 --pmc SQ_* passes at 48^3 cells)"}
-        out["roofline"] = {"kernel": "dg_stage_a_kernel<3,%d,Euler>" % N, "bound": "fp64-valu", "achieved": ach,
+            if rec.get("kernel") == kname:
+                pmc = {"valu_busy": rec["valu_issue_frac"], "lds_busy": rec["lds_array_busy_frac"], "mfma_busy": 0.0,
+                       "busy_source": "profiles/stage_a_pmc.json (rocprofv3 --pmc SQ_* passes at 48^3 cells)"}
+        out["roofline"] = {"kernel": s.stage_a_kernel_name(), "bound": "fp64-valu", "bound_basis": "algorithmic flops (SURVEY.md 8(d))", "achieved": ach,
                            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
                            "frac_of_measured_fma_loop": ach / FP64_MEASURED_TFLOPS, "traffic": traffic,
                            "traffic_source": src, "launch_ms": ta * 1e3, "launches_per_step": per_step, "flop_per_launch": work["flop_a"],
                            "hbm_achieved_gbs": work["bytes_a"] / ta / 1e9, "hbm_frac": work["bytes_a"] / ta / 1e9 / HBM_PEAK_GBS,
                            "hbm_frac_of_measured_copy": work["bytes_a"] / ta / 1e9 / HBM_MEASURED_GBS,
+                           "hbm_measured_gbs": (traffic / ta / 1e9) if traffic else None,
                            "note": "fp64-compute-bound (48 FLOP/B): priced against the 78.6 TFLOP/s fp64 vector peak; the kernel "
                                    "issues no MFMA (fp64 MFMA has the same peak and fills 28 % of a tile at N = 6)"}
         out["roofline"].update(pmc)
@@ -289,13 +301,14 @@ def run_cfg2(a, torch, exa, world, rank, local):
             out["cpu_reference_fv"] = cpu_reference_fv()
     if sharded:
         # the exchange (pack + RCCL send/recv) on the comm stream against the interior stage A on the compute stream
-        ex, ov = [], []
+        ex, ov, xp = [], [], []
         for ready, c0, c1, i0, i1 in s.exchange_events:
             cs, ce = ready.elapsed_time(c0), ready.elapsed_time(c1)
             is_, ie = ready.elapsed_time(i0), ready.elapsed_time(i1)
             ex.append(ce - cs)
             ov.append(max(0.0, min(ce, ie) - max(cs, is_)) / max(ce - cs, 1e-9))
-        mine = torch.tensor([sum(ex) / len(ex), sum(ov) / len(ov), ta * 1e3], dtype=torch.float64,
+            xp.append(max(0.0, ce - ie))               # what the exchange adds to the step: its end past the end of the interior stage A
+        mine = torch.tensor([sum(ex) / len(ex), sum(ov) / len(ov), ta * 1e3, sum(xp) / len(xp)], dtype=torch.float64,
                             device="cuda" if a.backend == "nccl" else "cpu")
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
@@ -309,6 +322,7 @@ def run_cfg2(a, torch, exa, world, rank, local):
         out["exchange_ms"] = max(float(v[0]) for v in allv)
         out["overlap_frac"] = min(float(v[1]) for v in allv)
         out["stage_a_ms"] = max(float(v[2]) for v in allv)
+        out["exposed_exchange_ms"] = max(float(v[3]) for v in allv)
     return out
 
 
@@ -340,7 +354,9 @@ def run_cfg1(a, torch, exa, local):
            "config": {"workload": "BASELINE configs[1]: 2D compressible Euler, ADER-DG p=3, 512x512 cells, volume + Riemann + corrector "
                                   "(n_picard = 0), fused single launch", "cells_per_gpu": nc[0] * nc[1], "order": 3, "n_vars": 5, "dt": dt},
            "finite": bool(torch.isfinite(s.u).all().item()),
-           "roofline": {"kernel": "dg_fused_single_kernel<4,Euler>", "bound": "hbm", "achieved": b_alg / tk / 1e9, "peak": HBM_PEAK_GBS,
+           "roofline": {"kernel": "dg_fused_single_kernel<4,Euler>", "bound": "hbm", "bound_basis": "algorithmic bytes (SURVEY.md 8(d): 3 840 B per cell); "
+                        "the fused kernel keeps the traces on chip, so its measured HBM rate (hbm_measured_gbs) is lower than `achieved`",
+                        "hbm_measured_gbs": (traffic / tk / 1e9) if traffic else None, "achieved": b_alg / tk / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": b_alg / tk / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": b_alg / tk / 1e9 / HBM_MEASURED_GBS,
                         "traffic": traffic, "traffic_source": src, "launch_ms": tk * 1e3, "bytes_per_launch": b_alg}}
     if not a.no_cpu_baseline:
@@ -370,6 +386,7 @@ def run_cfg4(a, torch, exa, local):
         lim.step(dt, mask)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    lim.check(wait=True)                                                   # (a step past the capacity would have kept the unlimited DG result)
     ta = sum(e0.elapsed_time(e1) for e0, e1 in s.stage_a_events) / steps * 1e-3
     work = s.work()
     dof = n ** 3 * N ** 3 * 5
@@ -381,7 +398,8 @@ def run_cfg4(a, torch, exa, local):
                                   "volume + Riemann + corrector, FV subcell limiter (15^3 patches) on a Bernoulli(0.05) troubled mask" % n,
                       "cells_per_gpu": n ** 3, "order": 7, "n_vars": 5, "dt": dt, "troubled_cells": int(cnt)},
            "finite": bool(torch.isfinite(s.u).all().item()),
-           "roofline": {"kernel": "dg_stage_a_stream_kernel<8,Euler>", "bound": "fp64-valu", "achieved": work["flop_a"] / ta / 1e12,
+           "roofline": {"kernel": "dg_stage_a_stream_kernel<8,Euler>", "bound": "fp64-valu", "bound_basis": "algorithmic flops (SURVEY.md 8(d))",
+                        "hbm_measured_gbs": (traffic / ta / 1e9) if traffic else None, "achieved": work["flop_a"] / ta / 1e12,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": work["flop_a"] / ta / 1e12 / FP64_PEAK_TFLOPS,
                         "frac_of_measured_fma_loop": work["flop_a"] / ta / 1e12 / FP64_MEASURED_TFLOPS, "traffic": traffic,
                         "traffic_source": src, "launch_ms": ta * 1e3, "flop_per_launch": work["flop_a"],
@@ -429,7 +447,9 @@ def run_fv_ref(a, torch, exa, local):
            "config": {"workload": "reference-native FV Rusanov time_step (Unit test/test.cpp shape): 2D, patch 4x4, halo 1, 5+5 variables, "
                                   "2^20 patches, faithful mode (bit-exact with the compiled reference)", "patches": n},
            "finite": bool(torch.isfinite(Q).all().item()),
-           "roofline": {"kernel": "fv_rusanov_kernel<2,EulerRef2D,faithful,staged,4x4>", "bound": "hbm", "achieved": b_alg / tk / 1e9,
+           "roofline": {"kernel": "fv_rusanov_kernel<2,EulerRef2D,faithful,staged,4x4>", "bound": "hbm", "bound_basis": "algorithmic bytes (patch + halo "
+                        "read once, n_real written once: 220 B per volume)", "hbm_measured_gbs": (traffic / tk / 1e9) if traffic else None,
+                        "achieved": b_alg / tk / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_alg / tk / 1e9 / HBM_PEAK_GBS,
                         "frac_of_measured_copy": b_alg / tk / 1e9 / HBM_MEASURED_GBS, "traffic": traffic, "traffic_source": src,
                         "launch_ms": tk * 1e3, "bytes_per_launch": b_alg}}
@@ -447,6 +467,8 @@ def main():
     ap.add_argument("--cells", type=int, default=128, help="cells per axis per GPU (default: BASELINE configs[2])")
     ap.add_argument("--order", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="cfg2 on one GPU: do not append the short cfg1 / cfg4 / fv-ref runs (`other_configs`) to the line")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path with host-staged exchange")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--self-exchange", action="store_true",
@@ -496,6 +518,26 @@ def main():
 
     if a.config == "cfg2":
         out = run_cfg2(a, torch, exa, world, rank, local)
+        if world == 1 and not a.self_exchange and not a.no_other_configs:
+            # the other rows of SURVEY.md 8(d), briefly, in the same (driver-run) invocation: value, ms per step and roofline of each;
+            # metric / value / config of the line stay those of cfg 2
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            b = argparse.Namespace(**vars(a))
+            b.no_cpu_baseline = True
+            b.steps, b.warmup = 3, 1
+            others = {}
+            for name, fn in (("cfg1", run_cfg1), ("cfg4", run_cfg4), ("fv-ref", run_fv_ref)):
+                try:
+                    r = fn(b, torch, exa, local)
+                    others[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "finite", "roofline")}
+                    others[name]["workload"] = r["config"]["workload"]
+                except Exception as e:                                     # a failing side line must not take the headline with it -- it says so
+                    others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                gc.collect()
+                torch.cuda.empty_cache()
+            out["other_configs"] = others
     elif a.config == "cfg1":
         out = run_cfg1(a, torch, exa, local)
     elif a.config == "cfg4":

@@ -35,6 +35,38 @@ UNITS = [
 ]
 
 
+class build_lock:
+    """Inter-process lock for a build directory: N ranks that import the package at once (bench.py --gpus N, torchrun) must not
+    compile into the same object files and link the same library together."""
+
+    def __init__(self, directory):
+        os.makedirs(directory, exist_ok=True)
+        self.path = os.path.join(directory, ".build.lock")
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
+def link_atomically(cmd_without_output, target):
+    """Run a link command into a temporary name and rename it into place: a reader never maps a half-written library, and a killed
+    hipcc leaves no truncated file behind under the final name."""
+    tmp = "%s.tmp.%d" % (target, os.getpid())
+    r = subprocess.run(cmd_without_output + ["-o", tmp], capture_output=True, text=True)
+    if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    os.replace(tmp, target)
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -103,17 +135,18 @@ def build(force=False, jobs=None, verbose=False):
     """Compile every unit (in parallel) and link the shared library; returns its path."""
     if not force and up_to_date():
         return LIB
-    os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
-    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda u: _compile(u, verbose), UNITS))
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
-    with open(STAMP, "w") as f:
-        f.write(_sources_digest() + "\n")
+    with build_lock(OBJ):
+        if not force and up_to_date():                # another process built it while this one waited for the lock
+            return LIB
+        jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+        with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+            objs = list(ex.map(lambda u: _compile(u, verbose), UNITS))
+        link_atomically([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs, LIB)
+        tmp = "%s.tmp.%d" % (STAMP, os.getpid())
+        with open(tmp, "w") as f:
+            f.write(_sources_digest() + "\n")
+        os.replace(tmp, STAMP)
     return LIB
 
 

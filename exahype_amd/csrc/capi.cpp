@@ -300,6 +300,11 @@ int exa_dg_plan_set_stage_a(exa_dg_plan* plan, int variant) {
     return EXA_OK;
 }
 
+const char* exa_dg_stage_a_kernel(const exa_dg_plan* plan) {
+    if (!plan || !plan->tab->stage_a_name) return "";
+    return plan->tab->stage_a_name(plan->N, plan->n_it, plan->ops.stage_a_variant);
+}
+
 long exa_dg_dof_count(const exa_dg_plan* p) { return p ? p->ncells * lpow(p->N, p->dim) * p->nv : 0; }
 long exa_dg_trace_count(const exa_dg_plan* p) { return p ? (long)p->dim * 2 * p->ncells * 2 * p->nv * lpow(p->N, p->dim - 1) : 0; }
 long exa_dg_face_count(const exa_dg_plan* p, int d) {

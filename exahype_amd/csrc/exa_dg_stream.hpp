@@ -411,6 +411,8 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                 EXA_STAMP(6);
 #ifdef EXA_STREAM_BARRIER4
                 __syncthreads();
+#else
+                static_assert(OH == 1, "two owners per node: the fold reads the co-owner's slot -- build with -DEXA_STREAM_BARRIER4");
 #endif
                 // (no barrier here: the next load phase writes Q and the flux scalars at the owner's OWN node, which only this lane
                 //  read in the fold above; the derive phase that read them across lanes ended two barriers ago)

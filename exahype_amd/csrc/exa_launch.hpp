@@ -44,6 +44,7 @@ struct DgLaunchTable {
     int (*maxeig)(const double* u, long nnodes, double* out, hipStream_t s);
     size_t (*ops_image)(int N, const DgOpsHost* h, void* dst);   // dst == nullptr: size only
     size_t (*scratch_bytes)(int N);                               // 0: the LDS kernel serves this N
+    const char* (*stage_a_name)(int N, int n_it, int variant);    // the kernel stage_a launches for these settings (profiles, bench line)
     // fused single-stage periodic step u_in -> u_out (2-D, n_picard = 0; exa_dg_fused.hpp), or nullptr
     int (*fused_single)(int N, const double* u_in, double* u_out, const long* nc, double dt, const double* idx,
                         const DgOpsHost* ops, hipStream_t s);

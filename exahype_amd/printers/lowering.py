@@ -227,15 +227,15 @@ class StatementLowering:
         so = os.path.join(d, "libexahype_generated.so")
         if os.path.exists(so) and not force:
             return so
-        os.makedirs(d, exist_ok=True)
-        src = os.path.join(d, "generated.hip")
-        with open(src, "w") as f:
-            f.write(self.source())
-        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        r = subprocess.run([hipcc, "-O3", "-fPIC", "-shared", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-ffp-contract=off",
-                            "-Wno-unused-variable", "-Wno-unused-value", src, "-o", so], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed for the generated kernels:\n%s" % r.stderr[-3000:])
+        with _build.build_lock(d):
+            if os.path.exists(so) and not force:          # another process built it meanwhile (renamed into place: complete)
+                return so
+            src = os.path.join(d, "generated.hip")
+            with open(src, "w") as f:
+                f.write(self.source())
+            hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+            _build.link_atomically([hipcc, "-O3", "-fPIC", "-shared", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-ffp-contract=off",
+                                    "-Wno-unused-variable", "-Wno-unused-value", src], so)
         return so
 
     # -- execution -----------------------------------------------------------------------------------------

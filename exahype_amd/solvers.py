@@ -271,7 +271,8 @@ class AderDgSolver:
         self.exchange_events = None
         if part is not None and any(part.partitioned(d) for d in range(dim)):
             self.halo = HaloExchange(part, self.nc, self.ts, self.dev, stage_through_host=backend_is_gloo)
-            self.comm_stream = torch.cuda.Stream(device=self.dev)
+            # high priority: the pack copies and the RCCL transport kernels must get CUs beside the persistent interior launch
+            self.comm_stream = torch.cuda.Stream(device=self.dev, priority=-1)
             self.shell, self.interior = part.shell_and_interior(self.nc)
 
     # -- data movement ---------------------------------------------------------------------
@@ -291,6 +292,10 @@ class AderDgSolver:
         out["N"] = N
         out["F0"] = out["phiL"].copy()
         return out
+
+    def stage_a_kernel_name(self):
+        """The kernel `predictor_volume` launches for this plan (as rocprofv3 names it, without the argument list)."""
+        return self.lib.exa_dg_stage_a_kernel(self._plan).decode()
 
     def work(self):
         v = [C.c_double() for _ in range(4)]
@@ -538,15 +543,27 @@ class SubcellLimiter:
     boundary layers, then -- only where the cell across the face is troubled -- the adjacent subcell layer of the
     boundary cells; the patches of troubled cells at a block face take their halo from those."""
 
+    DEFAULT_FRACTION = 0.1          # default capacity: this share of the block's cells (at least 16)
+
     def __init__(self, solver, capacity=None):
-        """capacity: upper bound of the number of troubled cells per step (default: every cell of the block); the FV
-        patch array [capacity][(N_s+2)^dim][n_vars] is allocated once (196 KB per patch at p = 7)."""
+        """capacity: upper bound of the number of troubled cells per step; the FV patch array [capacity][(N_s+2)^dim][n_vars]
+        is allocated once (196 KB per patch at p = 7) and the glue kernels launch `capacity` workgroups per step, so the
+        default is a bounded share of the block -- max(16, 10 % of its cells) -- not the whole block (262 144 cells at p = 7
+        would be 51 GB).  A step with more troubled cells than that is reported by check(): construct the limiter again with a
+        larger capacity (capacity=n_cells serves every mask).  Raises if the patch array does not fit the free device memory."""
         torch = _torch()
         self.s = solver
         self.Ns = 2 * solver.N - 1
         self.patch_doubles = solver.lib.exa_lim_patch_count(solver._plan)
         ncell = int(np.prod(solver.nc))
-        self.capacity = ncell if capacity is None else max(1, min(int(capacity), ncell))
+        if capacity is None:
+            capacity = max(16, int(self.DEFAULT_FRACTION * ncell))
+        self.capacity = max(1, min(int(capacity), ncell))
+        need = self.capacity * self.patch_doubles * 8
+        free = torch.cuda.mem_get_info(solver.dev)[0]
+        if need > free:
+            raise MemoryError("SubcellLimiter: capacity %d x %d B per patch = %.1f GB, %.1f GB of device memory are free; "
+                              "pass a smaller capacity" % (self.capacity, self.patch_doubles * 8, need / 1e9, free / 1e9))
         self._patches = torch.empty((self.capacity, self.patch_doubles), dtype=torch.float64, device=solver.dev)
         self._cells = torch.full((self.capacity + 1,), -1, dtype=torch.int64, device=solver.dev)     # + dump slot
         self._arange = torch.arange(ncell, dtype=torch.int64, device=solver.dev)
@@ -657,7 +674,7 @@ class SubcellLimiter:
         self._cells.fill_(-1)
         self._cells.scatter_(0, pos, self._arange)
         self._cells[cap] = -1
-        self.overflow = count > cap
+        self.overflow |= count > cap                           # sticky until check() has reported it
         self._post_overflow()
         cells = self._cells
         ghosts = None
@@ -680,9 +697,13 @@ class SubcellLimiter:
         self._ovf_event.record(torch.cuda.current_stream(self.s.dev))
 
     def check(self, wait=False):
-        """Raise if a finished step had more troubled cells than `capacity` (those beyond it kept the DG result).
-        Without `wait` only steps the GPU has already completed are looked at (no synchronisation)."""
+        """Raise if ANY step since the last report had more troubled cells than `capacity` (those beyond it kept the DG
+        result): the flag accumulates on the device and is cleared only here.  Without `wait` only steps the GPU has
+        already completed are looked at (no synchronisation)."""
         if wait:
             self._ovf_event.synchronize()
         if self._ovf_event.query() and bool(self._ovf_host[0]):
-            raise RuntimeError("SubcellLimiter: more troubled cells than capacity = %d" % self.capacity)
+            self.overflow = _torch().zeros((), dtype=_torch().bool, device=self.s.dev)      # reported: start over
+            self._ovf_host[0] = 0
+            raise RuntimeError("SubcellLimiter: a step since the last check() had more troubled cells than capacity = %d "
+                               "(those beyond it kept the unlimited DG result)" % self.capacity)

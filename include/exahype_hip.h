@@ -111,6 +111,9 @@ int exa_dg_plan_destroy(exa_dg_plan* plan);
 #define EXA_STAGE_A_LDS 1
 #define EXA_STAGE_A_REG 2
 int exa_dg_plan_set_stage_a(exa_dg_plan* plan, int variant);
+/* name of the kernel exa_dg_predictor_volume launches for this plan, as a profiler prints it without the argument list
+ * (static storage, valid until the next call); for bench lines and profile summaries */
+const char* exa_dg_stage_a_kernel(const exa_dg_plan* plan);
 long exa_dg_dof_count(const exa_dg_plan* plan);    /* doubles in u:      ncells * N^dim * n_vars */
 long exa_dg_trace_count(const exa_dg_plan* plan);  /* doubles in traces: dim*2*ncells*2*n_vars*N^(dim-1) */
 long exa_dg_face_count(const exa_dg_plan* plan, int d); /* doubles in one ghost/pack buffer for direction d */

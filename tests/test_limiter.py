@@ -119,6 +119,20 @@ def test_limiter_capacity_and_device_resident_mask():
     s2 = exa.AderDgSolver(dim, N, nc, dx=dx); s2.upload(u); s2.step(dt)
     a, b = s.download(), s2.download()
     assert np.array_equal(a[3, 3], b[3, 3]) and np.array_equal(a[0, 0], res[0][0, 0]) and np.array_equal(a[2, 1], res[0][2, 1])
+    # the flag is sticky: a later step within the capacity does not hide the overflow, and check() reports it once
+    s3 = exa.AderDgSolver(dim, N, nc, dx=dx)
+    lim3 = exa.SubcellLimiter(s3, capacity=2)
+    s3.upload(u)
+    lim3.step(dt, mask)
+    fewer = mask.copy()
+    fewer[3, 3] = False
+    lim3.step(dt, fewer)
+    with pytest.raises(RuntimeError, match="capacity"):
+        lim3.check(wait=True)
+    lim3.check(wait=True)
+    # default capacity: a bounded share of the block, not the block
+    big = exa.AderDgSolver(2, 3, (40, 40))
+    assert exa.SubcellLimiter(big).capacity == 160
 
 
 @pytest.mark.gpu
