@@ -29,6 +29,7 @@ SIGNATURES = {
     "exa_dg_plan_create": (C.c_int, [C.c_int] * 6 + [_lp, C.POINTER(_vp)]),
     "exa_dg_plan_set_stage_a": (C.c_int, [_vp, C.c_int]),
     "exa_dg_stage_a_kernel": (C.c_char_p, [_vp]),
+    "exa_dg_plan_set_stage_a_reserve": (C.c_int, [_vp, C.c_int]),
     "exa_dg_plan_destroy": (C.c_int, [_vp]),
     "exa_dg_dof_count": (C.c_long, [_vp]),
     "exa_dg_trace_count": (C.c_long, [_vp]),

@@ -261,6 +261,7 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
     }
     p->ops.scratch = nullptr;
     p->ops.lim = nullptr;
+    p->ops.stage_a_reserve = 0;
     p->ops.stage_a_variant = EXA_STAGE_A_AUTO;
     if (const char* ev = getenv("EXA_STAGE_A")) {
         if (!strcmp(ev, "lds")) p->ops.stage_a_variant = EXA_STAGE_A_LDS;
@@ -297,6 +298,12 @@ int exa_dg_plan_set_stage_a(exa_dg_plan* plan, int variant) {
         return EXA_ERR_INVALID;
     }
     plan->ops.stage_a_variant = variant;
+    return EXA_OK;
+}
+
+int exa_dg_plan_set_stage_a_reserve(exa_dg_plan* plan, int workgroups) {
+    if (!plan || workgroups < 0) { set_error("exa_dg_plan_set_stage_a_reserve: bad argument"); return EXA_ERR_INVALID; }
+    plan->ops.stage_a_reserve = workgroups;
     return EXA_OK;
 }
 

@@ -14,6 +14,7 @@ struct DgOpsHost {
     void* dev;     // DgOps<N> image in HBM (read by the kernels through the constant address space)
     void* lim;     // limiter tables in HBM: P[Ns][N] then R[N][Ns] (null until first use)
     void* scratch; // per-workgroup slabs of the level-streamed stage A (N whose cell image exceeds LDS), else null
+    int stage_a_reserve;   // workgroups the persistent stage-A grids stay below the resident count (CUs left to the exchange's kernels)
     int stage_a_variant;   // 0: the build's default; 1: LDS-resident space-time image; 2: register-resident iterate (where built: 3-D, N = 6)
 };
 // dg_operators_host.cpp: Gauss-Legendre nodes by Newton, barycentric derivative

@@ -8,6 +8,7 @@ intent, from a Peano enclave task (`exahype/printers/CPPPrinter.py:346`).  These
 classes play that role for the HIP kernels: they own nothing numerical.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -240,7 +241,7 @@ class AderDgSolver:
     STAGE_A = {"auto": 0, "lds": 1, "reg": 2}      # include/exahype_hip.h EXA_STAGE_A_*
 
     def __init__(self, dim, N, ncells, pde=PDE_EULER, n_vars=5, n_picard=-1, dx=None, device=0, part=None,
-                 backend_is_gloo=False, fused_single_stage=True, stage_a="auto"):
+                 backend_is_gloo=False, fused_single_stage=True, stage_a="auto", reserve_cus=None):
         torch = _torch()
         self.lib = _lib.load()
         self.dim, self.N, self.nv, self.pde = dim, N, n_vars, pde
@@ -271,8 +272,14 @@ class AderDgSolver:
         self.exchange_events = None
         if part is not None and any(part.partitioned(d) for d in range(dim)):
             self.halo = HaloExchange(part, self.nc, self.ts, self.dev, stage_through_host=backend_is_gloo)
-            # high priority: the pack copies and the RCCL transport kernels must get CUs beside the persistent interior launch
+            # High priority: the pack copies and the RCCL transport kernels are dispatched ahead of the persistent interior launch, which
+            # otherwise fills every CU first (measured on the RCCL-to-self rehearsal: the exchange span fell from 166 ms -- served as
+            # interior workgroups retired -- to 0.44 ms, profiles/r03_bench_cfg2_self_exchange.json).  `reserve_cus` > 0 additionally keeps
+            # the persistent grids that many workgroups below the resident count; it costs 0.4 % of stage A per CU and bought nothing
+            # in the rehearsal, so the default is 0 (EXA_RESERVE_CUS / the argument are there for a node where RCCL needs resident CUs).
             self.comm_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+            self.reserve_cus = int(os.environ.get("EXA_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
+            check(self.lib.exa_dg_plan_set_stage_a_reserve(h, self.reserve_cus))
             self.shell, self.interior = part.shell_and_interior(self.nc)
 
     # -- data movement ---------------------------------------------------------------------

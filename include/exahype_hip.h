@@ -111,6 +111,11 @@ int exa_dg_plan_destroy(exa_dg_plan* plan);
 #define EXA_STAGE_A_LDS 1
 #define EXA_STAGE_A_REG 2
 int exa_dg_plan_set_stage_a(exa_dg_plan* plan, int variant);
+/* Stage A of the larger orders runs as a persistent grid that fills every CU (one or two workgroups per CU, all of its LDS or
+ * registers): kernels on OTHER streams -- the face packing and the RCCL transport of a halo exchange that is meant to overlap the
+ * interior cells -- then only get CUs as those workgroups retire.  `workgroups` > 0 keeps the persistent grids that many workgroups
+ * below the resident count, i.e. leaves that many CUs free (0, the default: fill the chip). */
+int exa_dg_plan_set_stage_a_reserve(exa_dg_plan* plan, int workgroups);
 /* name of the kernel exa_dg_predictor_volume launches for this plan, as a profiler prints it without the argument list
  * (static storage, valid until the next call); for bench lines and profile summaries */
 const char* exa_dg_stage_a_kernel(const exa_dg_plan* plan);
