@@ -166,7 +166,7 @@ __device__ unsigned long long g_exa_wg_span[2 * 1024];     // per workgroup: sta
 #endif
 
 // s = M F for a centro-antisymmetric N x N matrix M given in its even-odd packing E (DgOps::DEO / KEO): half the FMAs.
-template <int N> __device__ inline void eo_apply(const double* E, const double (&F)[N], double (&s)[N]) {
+template <int N, class EP> __device__ inline void eo_apply(EP E, const double (&F)[N], double (&s)[N]) {
     constexpr int H = N / 2;
     double P[H > 0 ? H : 1], M[H > 0 ? H : 1];
 #pragma unroll

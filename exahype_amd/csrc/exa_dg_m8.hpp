@@ -1,0 +1,371 @@
+// Stage A for 3-D cells with N = 8 (p = 7, BASELINE configs[4]) with the derivative contraction on the MATRIX pipe and the whole
+// space-time iterate in registers -- nothing outside the chip (the level-streamed kernel of exa_dg_stream.hpp parks half of the
+// iterate in a lane-private slab in HBM / L2: 170 GB of L2 <-> fabric traffic per 64^3 launch against 18.8 GB algorithmic).  Same
+// scheme and results (to rounding) as dg_stage_a_stream_kernel<8>; no counterpart in the reference.
+//
+// The even-odd form of the centro-antisymmetric 8 x 8 derivative operator is two dense 4 x 4 blocks: with e_j = F_j + F_{7-j},
+// o_j = F_j - F_{7-j} (j < 4),  P = Ee e,  M = Eo o,  s_i = M_i + P_i,  s_{7-i} = M_i - P_i.  v_mfma_f64_4x4x4_4b_f64 multiplies four
+// independent 4 x 4 blocks per instruction with the operands spread over the lanes (A[i][k] in lane i + 4 blk + 16 k, B[k][c] in
+// lane c + 4 blk + 16 k, D[i][c] in lane c + 4 blk + 16 i: probed by scripts/mfma_n8_probe.hip), so FOUR lanes share a pencil:
+// lane (p = lane & 15, j = lane >> 4) loads the node pair (j, 7 - j) of pencil p, evaluates its two fluxes, hands e_j (o_j) to the
+// instruction as its B element and receives P_j (M_j) of ITS OWN pencil -- the sums of the nodes it loaded.  No cross-lane movement,
+// 100 % tile fill, the even-odd halving kept, bit-identical to the vector form (same FMA order).  Per pencil and variable 2 MFMAs
+// of 256 multiply-adds replace 32 vector FMAs; a derive task needs ~60 VGPRs instead of ~130 (no 4 x 5 x 2 accumulator block),
+// which is what lets the owner lanes keep all 8 levels of the iterate AND the 8 accumulators of the time contraction (160 VGPRs).
+// Measured beside the vector form on LDS-resident data: scripts/mfma_n8.hip, profiles/r03_mfma_n8.txt.
+//
+// Workgroup = 512 threads = 512 node owners, one per CU (156.7 KB of LDS), persistent grid.  A step takes two time levels:
+//   load    owners: q_l and the flux scalars of the two levels -> LDS (issued inside the previous fold)
+//   derive  three rounds (x, y, z), in each all 8 waves: wave w = pencils 16 w .. 16 w + 15 of the 128 (level slot, pencil) pairs;
+//           y -> A, z -> B, x stays in registers (10 values) and overwrites Q after the barrier
+//   fold    owners: acc[l'] += -dt T[l'][l] (S_x + S_y + S_z)_l, started from u: after the last step acc is the new iterate
+// LDS image and strides as exa_dg_stream.hpp (StreamGeo<8>: row stride 9, plane stride 72; Q | A | B | flux scalars).
+#pragma once
+#include "exa_dg_stream.hpp"
+
+namespace exa {
+
+// LDS strides: row stride 8, plane stride 70, level stride 560 -- with them the lane tables (dg_inst.hip fill_m8_tables) make every LDS
+// read of the two-level derive rounds conflict-free in all three directions.  A 32-lane ds_read_b64 group holds the node pairs k and
+// k + 1 of 16 pencils, so the pencils of a wave need bank residues R with R and R + stride disjoint: for a pencil stride s the
+// residues are 2-coloured along the cycles of r -> r + s (mod 32), four waves take one colour each.  (Strides 9 / 72 of
+// exa_dg_stream.hpp leave the x pencils 2- to 3-way conflicted in this lane mapping; found by search over the strides that fit.)
+struct M8Geo {
+    static constexpr int N = 8, NN = 512, NF = 64;
+    static constexpr int PY = 8, PX = 70, SL = 560;
+    __host__ __device__ static inline int node_off(int n) { return (n / NF) * PX + ((n / N) % N) * PY + n % N; }
+    __host__ __device__ static constexpr int pstride(int d) { return d == 0 ? PX : (d == 1 ? PY : 1); }
+    __host__ __device__ static inline int pbase(int d, int t) {
+        const int a = t / N, b = t - a * N;
+        return d == 0 ? a * PY + b : (d == 1 ? a * PX + b : a * PX + b * PY);
+    }
+};
+
+template <class PDE> struct StageAM8 {
+    static constexpr int N = 8;
+    using G = M8Geo;
+    static constexpr int NV = PDE::NV, NA = PDE::NAUX;
+    static constexpr int NT = 512, LG = 2, LS = N / LG;
+    static constexpr int VS = LG * G::SL;                             // slot stride
+    static constexpr int QSZ = NV * VS;                               // Q, A, B
+    static constexpr int AXO = 3 * QSZ;                               // flux scalars
+    static constexpr int PIC_D = 3 * QSZ + NA * VS;
+    static constexpr int FIN_D = (pde_has_source<PDE>::value ? 5 : 4) * NV * G::SL;
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(PIC_D > FIN_D ? PIC_D : FIN_D);
+    static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && G::NN == NT;
+    // lane tables behind the operator image: [levels in the step: 2, 1][direction][lane] -> level slot * SL + first node of the lane's pencil, -1 idle
+    static constexpr int TAB_INTS = 2 * 3 * NT;
+};
+
+template <class PDE>
+__global__ void __launch_bounds__(512)
+dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
+                     long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
+                     const void* __restrict__ ops_raw, const void* __restrict__ step_raw, const int* __restrict__ tab) {
+    constexpr int N = 8, H = 4, DIM = 3;
+    using G = M8Geo;
+    using SA = StageAM8<PDE>;
+    constexpr int NV = SA::NV, NA = SA::NA, NN = G::NN, NF = G::NF, SL = G::SL, VS = SA::VS, QSZ = SA::QSZ, AXO = SA::AXO, NT = SA::NT, LS = SA::LS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    [[maybe_unused]] const int bt = lane, grp = wave & 3;             // (stamp builds)
+    EXA_STAMP_INIT();
+
+    // owner slot -> node permutation that makes the node-linear LDS phases conflict-free under the padded strides (exa_dg_stream.hpp)
+    int o_n;
+    {
+        int* table = reinterpret_cast<int*>(lds);
+        const int n = tid, blk = n & ~255;
+        const int r = G::node_off(n) & 31;
+        int rank = 0;
+        for (int m = blk; m < n; m++) rank += ((G::node_off(m) & 31) == r) ? 1 : 0;
+        table[blk + rank * 32 + r] = n;
+        __syncthreads();
+        o_n = table[tid];
+        __syncthreads();
+    }
+    const int o_off = G::node_off(o_n);
+
+    // derive role: node pair j = lane >> 4 of the pencil the lane tables give this lane (one per direction; the 16 pencils of a wave
+    // have bank residues that keep the pairs k, k + 1 of a 32-lane group apart)
+    const int d_j = lane >> 4;
+    int d_off2[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) d_off2[d] = tab[d * NT + tid];
+    // A operands of this lane: Ee[k][i], Eo[k][i] with i = lane & 3, k = lane >> 4 (DgOps::DEO packing: [j][i] even part, [j][H + i] odd part)
+    const double aEe = static_cast<const DgOps<N>*>(ops_raw)->DEO[d_j * N + (lane & 3)];
+    const double aEo = static_cast<const DgOps<N>*>(ops_raw)->DEO[d_j * N + H + (lane & 3)];
+
+    // one round: direction D, results to A (D = 1), B (D = 2) or into hx (D = 0)
+    auto round = [&](auto dc, const int (&offs)[3], double (&hx)[2][NV]) {
+        constexpr int D = decltype(dc)::value;
+        if (offs[D] >= 0) {                                           // (wave-uniform: a wave has 16 pencils or none)
+            constexpr int ps = G::pstride(D);
+            const int off = opaque_v(offs[D]);
+            const int na = off + d_j * ps, nb = off + (N - 1 - d_j) * ps;
+            double qa[NV], qb[NV], aa[NA], ab[NA], Fa[NV], Fb[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                qa[v] = EXA_SLD(na + v * VS);
+                qb[v] = EXA_SLD(nb + v * VS);
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                aa[k] = EXA_SLD(AXO + na + k * VS);
+                ab[k] = EXA_SLD(AXO + nb + k * VS);
+            }
+            const double sc = D == 0 ? idx0 : (D == 1 ? idx1 : idx2);
+            PDE::template flux_scaled<D>(qa, aa, sc, Fa);
+            PDE::template flux_scaled<D>(qb, ab, sc, Fb);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
+                const double Pv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, e, 0.0, 0, 0, 0);
+                const double Mv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, o, 0.0, 0, 0, 0);
+                if constexpr (D == 0) {
+                    hx[0][v] = Mv + Pv;
+                    hx[1][v] = Mv - Pv;
+                } else {
+                    lds[D * QSZ + na + v * VS] = Mv + Pv;
+                    lds[D * QSZ + nb + v * VS] = Mv - Pv;
+                }
+            }
+        }
+    };
+    auto derive = [&](const int (&offs)[3]) {
+        double hx[2][NV];
+        round(std::integral_constant<int, 1>{}, offs, hx);
+        round(std::integral_constant<int, 2>{}, offs, hx);
+        round(std::integral_constant<int, 0>{}, offs, hx);           // x last: its sums wait in registers for the barrier
+        __syncthreads();                                              // every read of Q is done; S_y (A), S_z (B) are complete
+        if (offs[0] >= 0) {                                           // Q := S_x
+            constexpr int ps = G::pstride(0);
+            const int off = opaque_v(offs[0]);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                lds[off + d_j * ps + v * VS] = hx[0][v];
+                lds[off + (N - 1 - d_j) * ps + v * VS] = hx[1][v];
+            }
+        }
+        __syncthreads();
+    };
+    auto put_level = [&](int ls, const double (&qv)[NV]) {
+        double a[NA];
+        PDE::aux_fast(qv, a);
+#pragma unroll
+        for (int v = 0; v < NV; v++) lds[o_off + ls * SL + v * VS] = qv[v];
+#pragma unroll
+        for (int k = 0; k < NA; k++) lds[AXO + o_off + ls * SL + k * VS] = a[k];
+    };
+
+    for (long b = blockIdx.x; b < box.nbox; b += gridDim.x) {
+        const long cell = box.cell(b);
+        const double* up = u_in + (cell * NN + o_n) * NV;             // (u is re-read where needed: an L2 hit against 10 VGPRs of a kernel at its cap)
+        double u[NV], q[N][NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) u[v] = up[v];
+
+        // ---- Picard iteration 0: the iterate is constant in time -- one level, row sums of T
+        put_level(0, u);
+        EXA_STAMP(0);
+        __syncthreads();
+        EXA_STAMP(1);
+        {
+            int d_off1[3];                                            // iteration 0 has its own table (one level: four waves per round)
+#pragma unroll
+            for (int d = 0; d < 3; d++) d_off1[d] = tab[(3 + d) * NT + tid];
+            derive(d_off1);
+        }
+        EXA_STAMP(2);
+        {
+            double S[NV], Ts[N];
+            sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                const int p = o_off + v * VS;
+                const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
+                S[v] = sx + (sy + sz);
+            }
+            if constexpr (pde_has_source<PDE>::value) {
+                double Sq[NV];
+                PDE::source(u, Sq);
+#pragma unroll
+                for (int v = 0; v < NV; v++) S[v] -= Sq[v];
+            }
+#pragma unroll
+            for (int l = 0; l < N; l++)
+#pragma unroll
+                for (int v = 0; v < NV; v++) q[l][v] = fma(Ts[l], S[v], u[v]);
+        }
+        EXA_STAMP(3);
+
+        // ---- Picard iterations 1 .. n_it - 1: steps of two levels; the load of the next step's levels sits inside the fold
+        [[maybe_unused]] double Sq[2][NV], Sqn[2][NV];
+        auto load_levels = [&](auto lc, const double (&qq)[N][NV], double (&S2)[2][NV]) {
+            constexpr int l0 = decltype(lc)::value;
+#pragma unroll
+            for (int ls = 0; ls < 2; ls++) {
+                put_level(ls, qq[l0 + ls]);
+                if constexpr (pde_has_source<PDE>::value) PDE::source(qq[l0 + ls], S2[ls]);
+            }
+        };
+        if (n_it > 1) load_levels(std::integral_constant<int, 0>{}, q, Sq);
+        for (int it = 1; it < n_it; it++) {
+            double acc[N][NV];
+            static_for<0, LS>([&](auto sc_) {
+                constexpr int st = decltype(sc_)::value;
+                constexpr int l0 = 2 * st;
+                EXA_STAMP(4);
+                __syncthreads();
+                EXA_STAMP(5);
+                derive(d_off2);
+                EXA_STAMP(6);
+                double Tm[2 * N];                                      // -dt T[l'][l0 + ls], l' fastest
+                sload<2 * N>(step_here<N>(step_raw)->TdtT + l0 * N, Tm);
+                [[maybe_unused]] double uu[NV];
+                if constexpr (st == 0) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++) uu[v] = up[v];
+                }
+                double Sx[2][NV];                                      // (summed as they arrive: 160 VGPRs of iterate + accumulators leave no room for 30 loads in flight)
+#pragma unroll
+                for (int ls = 0; ls < 2; ls++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        const int p = o_off + ls * SL + v * VS;
+                        const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
+                        Sx[ls][v] = sx + (sy + sz);
+                        if constexpr (pde_has_source<PDE>::value) Sx[ls][v] -= Sq[ls][v];
+                    }
+                if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q, Sqn);
+#pragma unroll
+                for (int ls = 0; ls < 2; ls++)
+#pragma unroll
+                    for (int lp = 0; lp < N; lp++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            if constexpr (st == 0) acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], ls == 0 ? uu[v] : acc[lp][v]);
+                            else acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], acc[lp][v]);
+                        }
+                if constexpr (pde_has_source<PDE>::value) {
+#pragma unroll
+                    for (int ls = 0; ls < 2; ls++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) Sq[ls][v] = Sqn[ls][v];
+                }
+                if constexpr (st + 1 == LS) {
+                    if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, acc, Sq);
+                }
+                EXA_STAMP(7);
+            });
+#pragma unroll
+            for (int l = 0; l < N; l++)
+#pragma unroll
+                for (int v = 0; v < NV; v++) q[l][v] = acc[l][v];
+        }
+
+        // ---- time averages: qbar | Fbar_x | Fbar_y | Fbar_z (| time-averaged source)
+        __syncthreads();                                              // every fold has read its sums: the closing image reuses the LDS
+        {
+            double wm[N];
+            sload<N>(ops_here<N>(ops_raw)->w, wm);
+            double qb[NV], Fb[DIM][NV];
+            [[maybe_unused]] double Sbar[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) qb[v] = 0.0;
+#pragma unroll
+            for (int d = 0; d < DIM; d++)
+#pragma unroll
+                for (int v = 0; v < NV; v++) Fb[d][v] = 0.0;
+            if constexpr (pde_has_source<PDE>::value) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) Sbar[v] = 0.0;
+            }
+#pragma unroll
+            for (int l = 0; l < N; l++) {
+                double a[NA], F[NV];
+                PDE::aux_fast(q[l], a);
+#pragma unroll
+                for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[l][v];
+                static_for<0, DIM>([&](auto dc) {
+                    constexpr int D = decltype(dc)::value;
+                    PDE::template flux<D>(q[l], a, F);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) Fb[D][v] += wm[l] * F[v];
+                });
+                if constexpr (pde_has_source<PDE>::value) {
+                    double S1[NV];
+                    PDE::source(q[l], S1);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) Sbar[v] += wm[l] * S1[v];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                lds[v * SL + o_off] = qb[v];
+#pragma unroll
+                for (int d = 0; d < DIM; d++) lds[((1 + d) * NV + v) * SL + o_off] = Fb[d][v];
+                if constexpr (pde_has_source<PDE>::value) lds[(4 * NV + v) * SL + o_off] = Sbar[v];
+            }
+        }
+        EXA_STAMP(8);
+        __syncthreads();
+
+        // ---- volume integral (in place over Fbar_d) + face extrapolation: pencil tasks (d, v, t), t fastest
+        {
+            // (the operator entries are fetched next to their use: KEO | 1/w | phiL | phiR together are 61 doubles, more than the SGPR file)
+            const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
+            for (int task = tid; task < DIM * NV * NF; task += NT) {
+                const int d = task / (NV * NF);
+                const int r = task - d * (NV * NF);
+                const int v = r / NF, t = r - v * NF;
+                const int ps = G::pstride(d);
+                const int pb = G::pbase(d, t);
+                double qb[N], Fb[N], vol[N];
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    qb[j] = EXA_SLD(v * SL + pb + j * ps);
+                    Fb[j] = EXA_SLD(((1 + d) * NV + v) * SL + pb + j * ps);
+                }
+                eo_apply<N>(o->KEO, Fb, vol);
+                const double sc = dt * (d == 0 ? idx0 : (d == 1 ? idx1 : idx2));
+#pragma unroll
+                for (int i = 0; i < N; i++) lds[((1 + d) * NV + v) * SL + pb + i * ps] = sc * o->iw[i] * vol[i];
+                double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    qL += o->phiL[j] * qb[j];
+                    qR += o->phiR[j] * qb[j];
+                    FL += o->phiL[j] * Fb[j];
+                    FR += o->phiR[j] * Fb[j];
+                }
+                double* tl = trace + (((long)d * 2 + 0) * ncells + cell) * (2 * NV * NF);
+                double* tr = trace + (((long)d * 2 + 1) * ncells + cell) * (2 * NV * NF);
+                tl[(0 * NV + v) * NF + t] = qL;
+                tl[(1 * NV + v) * NF + t] = FL;
+                tr[(0 * NV + v) * NF + t] = qR;
+                tr[(1 * NV + v) * NF + t] = FR;
+            }
+        }
+        EXA_STAMP(9);
+        __syncthreads();
+
+        // ---- u* = u + sum_d vol_d (+ dt * time-averaged source): each owner its node
+        {
+            double* uo = u_out + (cell * NN + o_n) * NV;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                double us = up[v];
+                if constexpr (pde_has_source<PDE>::value) us += dt * EXA_SLD((4 * NV + v) * SL + o_off);
+#pragma unroll
+                for (int d = 0; d < DIM; d++) us += EXA_SLD(((1 + d) * NV + v) * SL + o_off);
+                uo[v] = us;
+            }
+        }
+        __syncthreads();                                              // LDS is reused by the next cell
+        EXA_STAMP(10);
+    }
+    EXA_STAMP_FLUSH();
+}
+
+}  // namespace exa

@@ -14,10 +14,13 @@ namespace exa { void set_error(const char* fmt, ...) { va_list ap; va_start(ap, 
 using namespace exa;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv) {
-    constexpr int N = 6;
+#ifndef BN
+#define BN 6                                  // -DBN=8: the N = 8 kernels (exa_dg_m8.hpp against exa_dg_stream.hpp)
+#endif
+    constexpr int N = BN, NN3 = N * N * N, NF2 = N * N;
     const long nc = argc > 1 ? atol(argv[1]) : 64, ncells = nc * nc * nc;
     const int rounds = argc > 2 ? atoi(argv[2]) : 3;
-    const long ndof = ncells * 216 * 5, ntr = 3 * 2 * ncells * 2 * 5 * 36;
+    const long ndof = ncells * NN3 * 5, ntr = 3 * 2 * ncells * 2 * 5 * NF2;
     std::vector<double> h(ndof);
     std::mt19937_64 rng(4);
     std::uniform_real_distribution<double> U(0.0, 1.0);
@@ -33,7 +36,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&ops.dev, ob)); CK(hipMemcpy(ops.dev, img.data(), ob, hipMemcpyHostToDevice));
     CellBox box; for (int d = 0; d < 3; d++) { box.nc[d] = nc; box.lo[d] = 0; box.nb[d] = nc; } box.nbox = ncells;
     const double dx = 1.0 / nc, idx[3] = {1 / dx, 1 / dx, 1 / dx}, dt = 0.05 * dx / (2 * N - 1) / 3 / 2.5;
-    const double flop = 2449440.0 * ncells;
+    const double Nd = NN3, flop = (N * (2.0 * 4 * 5 * Nd * N * N + 3 * 20.0 * Nd * N) + 2.0 * 4 * 5 * Nd * N + 2.0 * 3 * 5 * Nd * N + 8.0 * 3 * 5 * Nd) * ncells;   // exa_dg_work()
+    if (N > 6) { ops.scratch = nullptr; CK(hipMalloc(&ops.scratch, scratch_bytes(N))); }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<double> ref;
     for (int r = 0; r < rounds + 1; r++)
@@ -49,8 +53,8 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r == 0) {                                                // first round: warm-up and cross-check of the two kernels
-                std::vector<double> out(216 * 5 * 64);
-                CK(hipMemcpy(out.data(), u + (ncells / 2) * 1080, out.size() * 8, hipMemcpyDeviceToHost));
+                std::vector<double> out(NN3 * 5 * 64);
+                CK(hipMemcpy(out.data(), u + (ncells / 2) * NN3 * 5, out.size() * 8, hipMemcpyDeviceToHost));
                 if (variant == 2) ref = out;
                 else { double e = 0; for (size_t i = 0; i < out.size(); i++) e = std::max(e, std::abs(out[i] - ref[i])); printf("max |reg - lds| over 64 cells: %.3e\n", e); }
                 continue;
@@ -59,7 +63,11 @@ int main(int argc, char** argv) {
 #ifdef EXA_STAMPS
             if (variant == 2 && r == rounds) {
                 CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_exa_stamps), sizeof(z)));
+#if BN == 8
+                const char* names[12] = {"it0 load", "it0 barrier", "it0 derive", "it0 fold", "(fold tail)", "barrier", "derive", "fold+load", "averages", "vol+traces", "u* store", "-"};
+#else
                 const char* names[12] = {"it0 load", "it0 barrier", "it0 derive", "it0 barrier", "it0 fold", "load", "barrier", "derive", "barrier", "fold", "averages", "vol+traces"};
+#endif
                 printf("cycles per cell (waves 0..3):\n");
                 double tot[4] = {0};
                 for (int k = 0; k < 12; k++) { printf("   %-12s", names[k]); for (int w = 0; w < 4; w++) { printf(" %9.0f", (double)z[w * 12 + k] / ncells); tot[w] += (double)z[w * 12 + k] / ncells; } printf("\n"); }

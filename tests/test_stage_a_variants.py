@@ -59,6 +59,27 @@ def test_stage_a_variant_vs_oracle(exa, orc, variant, nc, n_it):
     assert rel_err(s.download().reshape(-1), uo) < TOL
 
 
+@pytest.mark.parametrize("variant", ["reg", "lds"])
+@pytest.mark.parametrize("nc,n_it", [((1, 2, 2), -1), ((2, 1, 1), 1), ((2, 2, 1), 3), ((7, 7, 6), -1)])
+def test_stage_a_variant_n8_vs_oracle(exa, orc, variant, nc, n_it):
+    """cfg 4's order (N = 8): "reg" = the matrix-pipe kernel with the iterate in registers (exa_dg_m8.hpp), "lds" = the level-streamed
+    kernel with the slab (exa_dg_stream.hpp); 294 cells > 256 resident workgroups in the last case."""
+    from oracle.dg_operators import operators
+    N8 = 8
+    ops = operators(N8)
+    u = euler_dg_state(tuple(nc) + (N8,) * 3, seed=800 + sum(nc))
+    dx = [1.0 / nc[0], 0.9 / nc[1], 1.2 / nc[2]]
+    dt = 0.02 * min(dx) / (2 * N8 - 1)
+    nit = N8 if n_it < 0 else n_it
+    s = exa.AderDgSolver(3, N8, nc, n_picard=n_it, dx=dx, stage_a=variant)
+    assert ("m8" in s.stage_a_kernel_name()) == (variant == "reg")
+    s.upload(u)
+    s.predictor_volume(dt)
+    us_o, tr_o = orc.aderdg_stage_a(u.reshape(-1), dt, dx, ops, 3, N8, 5, orc.PDE_EULER, nit)
+    assert rel_err(s.download().reshape(-1), us_o) < TOL
+    assert rel_err(s.trace.cpu().numpy().reshape(tr_o.shape), tr_o) < TOL
+
+
 def test_stage_a_variants_agree_on_boxes(exa):
     """shell / interior box launches of the 2x2x2 partition: both kernels, box by box, give the same block (to rounding)."""
     nc = (9, 8, 7)
