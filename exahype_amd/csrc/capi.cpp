@@ -40,15 +40,15 @@ struct UserPde {
     void* handle;
     const DgLaunchTable* dg[4];
     int nv;
-    int (*fv)(int, int, int, int, int, int, long, double*, double, double, const long*, void*);
+    int (*fv)(int, int, int, int, int, int, long, double*, double, double, const long*, void*, double*, const double*, double);
     int (*ev)(int, long, int, const double*, double*, double*, void*);
 };
 static std::vector<UserPde> g_user;
 
 int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                   double h, const long* slot, hipStream_t s) {
+                   double h, const long* slot, hipStream_t s, double* out, const double* centre, double t) {
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].fv) { set_error("pde %d is not registered", pde); return -1; }
-    return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, (void*)s);
+    return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, (void*)s, out, centre, t);
 }
 int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s) {
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].ev) { set_error("pde %d is not registered", pde); return -1; }
@@ -189,6 +189,21 @@ int exa_fv_time_step_device_masked(exa_fv_plan* p, double* Q_dev, const long* sl
     int rc = use_device(p->device);
     if (rc) return rc;
     return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, dt, h, slot_dev, (hipStream_t)stream);
+}
+
+int exa_fv_time_step_device_oop(exa_fv_plan* p, const double* QIn_dev, double* QOut_dev, const double* centre_dev, double t, double dt,
+                                double h, void* stream) {
+    if (!p || ((!QIn_dev || !QOut_dev) && p->count > 0)) { set_error("exa_fv_time_step_device_oop: NULL argument"); return EXA_ERR_INVALID; }
+    if (!(h > 0.0)) { set_error("exa_fv_time_step_device_oop needs the volume size h > 0 (volume centres, dt / h)"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    // (the kernel only reads QIn: the const is cast away for the signature it shares with the in-place call)
+    return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, const_cast<double*>(QIn_dev), dt, h, nullptr,
+                     (hipStream_t)stream, QOut_dev, centre_dev, t);
+}
+
+long exa_fv_qout_count(const exa_fv_plan* plan) {
+    return plan ? plan->n_patches * lpow(plan->P, plan->dim) * (plan->n_real + plan->n_aux) : 0;
 }
 
 int exa_fv_time_step_device(exa_fv_plan* p, double* Q_dev, double dt, double h, void* stream) {

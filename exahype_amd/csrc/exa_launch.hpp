@@ -55,13 +55,14 @@ const DgLaunchTable* dg_launch_table(int dim, int pde);
 
 // fv_rusanov.hip
 // slot: nullptr, or one entry per patch (< 0: patch not in use, left untouched)
+// out != nullptr: out of place (QOut halo-less, [patch][P^dim][n_real + n_aux]); centre: [patch][dim] cell centres or nullptr; t: time
 int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
-              double h, const long* slot, hipStream_t s);
+              double h, const long* slot, hipStream_t s, double* out = nullptr, const double* centre = nullptr, double t = 0.0);
 int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
 
 // user PDE term sets registered at run time (capi.cpp: exa_register_pde), pde ids >= 100
 int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                   double h, const long* slot, hipStream_t s);
+                   double h, const long* slot, hipStream_t s, double* out, const double* centre, double t);
 int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
 
 void set_error(const char* fmt, ...);

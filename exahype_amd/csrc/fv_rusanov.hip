@@ -36,6 +36,32 @@ template <int I, int E, class F> __device__ inline void static_for_fv(F&& f) {
     }
 }
 
+// Optional members of a PDE struct: `static constexpr bool HAS_XT = true` with flux_xt(q, x, t, d, F), maxeig_xt(q, x, t, d) and (with
+// HAS_SOURCE) source_xt(q, x, t, S) -- the terms may depend on the volume centre x[3] and the time t, as the hooks of the reference's
+// harness are declared (`Unit test/correctness_test.cpp:16-41`: flux / maxEigenvalue / sourceTerm(Q, x, h, t, dt, ...)).  The built-in
+// term sets have none, and for them the coordinates below are dead code: their kernels are unchanged.
+template <class P, class = void> struct pde_has_xt : std::false_type {};
+template <class P> struct pde_has_xt<P, std::void_t<decltype(P::HAS_XT)>> : std::bool_constant<P::HAS_XT> {};
+template <class PDE> __device__ inline void fv_flux(const double* q, const double* x, double t, int d, double* F) {
+    if constexpr (pde_has_xt<PDE>::value) PDE::flux_xt(q, x, t, d, F);
+    else PDE::flux_rt(q, d, F);
+}
+template <class PDE> __device__ inline double fv_eig(const double* q, const double* x, double t, int d) {
+    if constexpr (pde_has_xt<PDE>::value) return PDE::maxeig_xt(q, x, t, d);
+    else return PDE::maxeig(q, d);
+}
+template <class PDE> __device__ inline void fv_source(const double* q, const double* x, double t, double* S) {
+    if constexpr (pde_has_xt<PDE>::value) PDE::source_xt(q, x, t, S);
+    else PDE::source(q, S);
+}
+// What the `exahype2::CellData` flavour of the kernel adds to (Q, dt) (`exahype/KernelBuilder.py:217-218`, `Unit test/correctness_test.cpp:142`):
+// a separate, halo-less output array, the patch centres and the time.  All null / zero for the in-place call.
+struct FvCellData {
+    double* out;              // QOut[patch][P^dim][n_real + n_aux], or null: Q is updated in place
+    const double* centre;     // [patch][dim] cell centres, or null: every patch is centred at the origin
+    double t, h;              // time; volume size
+};
+
 // STAGE = true (small patches): the workgroup's `ppb` patches are one contiguous block of HBM; it is
 // copied into LDS with coalesced 16-byte loads and the stencil reads LDS (the AoS stencil reads straight
 // from HBM touch ~40 cache lines per wave instruction: 1.7 TB/s; staged: see DESIGN.md 4.3).
@@ -55,7 +81,7 @@ constexpr int FV_HR = 16;          // double2 per thread that hold a block in fl
 template <int DIM, class PDE, int MODE, int CPT, int NT, bool STAGE, class SHAPE = FvRuntimeShape, bool PERSIST = false>
 __global__ void __launch_bounds__(NT)
 fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt, double dt, double dt_over_h, long n_patches,
-                  int ppb, const long* __restrict__ slot) {
+                  int ppb, const long* __restrict__ slot, FvCellData cd) {
     const int P = SHAPE::P ? SHAPE::P : P_rt, H = SHAPE::P ? SHAPE::H : H_rt;
     const int m = SHAPE::P ? SHAPE::M : m_rt, V = SHAPE::P ? SHAPE::V : V_rt;
     extern __shared__ __attribute__((aligned(16))) double fv_lds[];
@@ -136,6 +162,16 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
         else { co[0] = id / P + H; co[1] = id % P + H; co[2] = 0; }
         const long c = co[0] * st[0] + co[1] * st[1] + co[2] * st[2];
         cidx[k] = c;
+        // centre of the volume (exahype2::fv::getVolumeCentre: patch centre - half the patch + (index + 1/2) h) and of its 2 dim neighbours
+        [[maybe_unused]] double xc[3] = {0.0, 0.0, 0.0};
+        if constexpr (pde_has_xt<PDE>::value) {
+#pragma unroll
+            for (int a = 0; a < DIM; a++) xc[a] = (cd.centre ? cd.centre[patch * DIM + a] : 0.0) + (co[a] - H + 0.5 - 0.5 * P) * cd.h;
+        }
+        auto shifted = [&](int d, double sgn, double (&xs)[3]) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) xs[a] = xc[a] + (a == d ? sgn * cd.h : 0.0);
+        };
         double qc[MAXV];
 #pragma unroll
         for (int v = 0; v < MAXV; v++) qc[v] = v < m ? Qp[c * V + v] : 0.0;
@@ -157,8 +193,10 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
                     qP[v] = v < m ? Qp[(c + st[d]) * V + v] : 0.0;
                     qM[v] = v < m ? Qp[(c - st[d]) * V + v] : 0.0;
                 }
-                if (co[d] + 1 < P + H) PDE::flux_rt(qP, d, Fp);
-                if (co[d] - 1 >= H) PDE::flux_rt(qM, d, Fm);
+                [[maybe_unused]] double xp[3], xm[3];
+                if constexpr (pde_has_xt<PDE>::value) { shifted(d, 1.0, xp); shifted(d, -1.0, xm); }
+                if (co[d] + 1 < P + H) fv_flux<PDE>(qP, xp, cd.t, d, Fp);
+                if (co[d] - 1 >= H) fv_flux<PDE>(qM, xm, cd.t, d, Fm);
 #pragma unroll
                 for (int v = 0; v < MAXV; v++) acc[v] = acc[v] - 0.5 * Fp[v] + 0.5 * Fm[v];
             }
@@ -171,9 +209,11 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
                     qP[v] = v < m ? Qp[(c + st[d]) * V + v] : 0.0;
                     qM[v] = v < m ? Qp[(c - st[d]) * V + v] : 0.0;
                 }
-                const double lc = PDE::maxeig(qc, d);
-                const double lp = (co[d] + 1 < P + H) ? PDE::maxeig(qP, d) : 0.0;
-                const double lm = (co[d] - 1 >= H) ? PDE::maxeig(qM, d) : 0.0;
+                [[maybe_unused]] double xp[3], xm[3];
+                if constexpr (pde_has_xt<PDE>::value) { shifted(d, 1.0, xp); shifted(d, -1.0, xm); }
+                const double lc = fv_eig<PDE>(qc, xc, cd.t, d);
+                const double lp = (co[d] + 1 < P + H) ? fv_eig<PDE>(qP, xp, cd.t, d) : 0.0;
+                const double lm = (co[d] - 1 >= H) ? fv_eig<PDE>(qM, xm, cd.t, d) : 0.0;
                 const double mp = lp > lc ? lp : lc;     // Functions.cpp:64-66 std::max(*a,*b)
                 const double mm = lm > lc ? lm : lc;
                 const double qp0 = qP[0], qm0 = qM[0], q0 = qc[0];
@@ -194,20 +234,22 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
                     qmp[v] = v < m ? Qp[(c - st[d]) * V + v] : 0.0;
                 }
                 const double* qcp = qc;
-                const double lc = PDE::maxeig(qcp, d);
-                const double sp = fmax(lc, PDE::maxeig(qpp, d));
-                const double sm = fmax(PDE::maxeig(qmp, d), lc);
+                [[maybe_unused]] double xp[3], xm[3];
+                if constexpr (pde_has_xt<PDE>::value) { shifted(d, 1.0, xp); shifted(d, -1.0, xm); }
+                const double lc = fv_eig<PDE>(qcp, xc, cd.t, d);
+                const double sp = fmax(lc, fv_eig<PDE>(qpp, xp, cd.t, d));
+                const double sm = fmax(fv_eig<PDE>(qmp, xm, cd.t, d), lc);
                 double Fc[MAXV], Fn[MAXV];
 #pragma unroll
                 for (int v = 0; v < MAXV; v++) { Fc[v] = 0.0; Fn[v] = 0.0; }
-                PDE::flux_rt(qcp, d, Fc);
-                PDE::flux_rt(qpp, d, Fn);
+                fv_flux<PDE>(qcp, xc, cd.t, d, Fc);
+                fv_flux<PDE>(qpp, xp, cd.t, d, Fn);
 #pragma unroll
                 for (int v = 0; v < MAXV; v++)
                     if (v < m) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sp * (qpp[v] - qc[v]);
 #pragma unroll
                 for (int v = 0; v < MAXV; v++) Fn[v] = 0.0;
-                PDE::flux_rt(qmp, d, Fn);
+                fv_flux<PDE>(qmp, xm, cd.t, d, Fn);
 #pragma unroll
                 for (int v = 0; v < MAXV; v++)
                     if (v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qmp[v]);
@@ -218,12 +260,28 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
                 double Sq[MAXV];
 #pragma unroll
                 for (int v = 0; v < MAXV; v++) Sq[v] = 0.0;
-                PDE::source(qc, Sq);
+                fv_source<PDE>(qc, xc, cd.t, Sq);
 #pragma unroll
                 for (int v = 0; v < MAXV; v++)
                     if (v < m) nv[k][v] += dt * Sq[v];
             }
         }
+    }
+    if (cd.out) {
+        // out of place (the CellData flavour): QOut is halo-less, [patch][volume][n_real + n_aux] -- thread order is volume order, every
+        // thread writes the V contiguous doubles of its volume (evolved variables updated, auxiliary ones copied): fully coalesced
+#pragma unroll
+        for (int k = 0; k < CPT; k++) {
+            if (cidx[k] < 0) continue;
+            const int id = (CPT == 1) ? (int)threadIdx.x - pl * ncell : (int)threadIdx.x + k * NT;
+            double* o = cd.out + (patch * ncell + id) * V;
+#pragma unroll
+            for (int v = 0; v < MAXV; v++)
+                if (v < m) o[v] = nv[k][v];
+            for (int v = m; v < V; v++) o[v] = Qp[cidx[k] * V + v];
+        }
+        if constexpr (PERSIST) __syncthreads();                  // the LDS copy is free for the next block
+        continue;
     }
     // every read of this patch is done (loads feed the values above) before any write
     __syncthreads();
@@ -618,7 +676,8 @@ __global__ void pde_eval_kernel(int normal, long n, int stride, const double* __
 }
 
 template <int DIM, class PDE, int MODE>
-static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, const long* slot, hipStream_t s) {
+static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, const long* slot, hipStream_t s,
+                       const FvCellData& cd) {
     const long ncell = (DIM == 3) ? (long)P * P * P : (long)P * P;
     const double doh = (MODE == 1) ? dt / h : 0.0;
     const int S = P + 2 * H;
@@ -629,7 +688,7 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
         const size_t lds = (size_t)ppb * pvol * V * sizeof(double);
         // persistent form (next block requested into registers during the update of this one): Q 16-byte aligned, an even
         // number of doubles per block, a grid that fills the chip once
-        const bool persist = lds <= 64 * 1024 && ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (((long)ppb * pvol * V) % 2 == 0) &&
+        const bool persist = !cd.out && lds <= 64 * 1024 && ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (((long)ppb * pvol * V) % 2 == 0) &&
                              n_patches >= (long)ppb * 2048;
         auto persist_grid = [&](const void* kern) -> unsigned {
             int per_cu = 0, dev = 0, cus = 0;
@@ -642,20 +701,20 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
         if (DIM == 2 && P == 4 && H == 1 && m == 5 && V == 10) {    // the reference's configuration (Batched_stateless.py:9)
             auto kp = fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>, true>;
             const unsigned pg = persist ? persist_grid(reinterpret_cast<const void*>(kp)) : 0;
-            if (pg > 0) hipLaunchKernelGGL(kp, dim3(pg), dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
-            else hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
+            if (pg > 0) hipLaunchKernelGGL(kp, dim3(pg), dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot, cd);
+            else hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot, cd);
         } else if (lds <= 64 * 1024)     // staged: several workgroups per CU keep HBM requests in flight (the persistent form
                                          // with its 64 holding VGPRs lost there: 2-D P = 16 0.55 -> 0.67 ms)
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true>), grid, dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot, cd);
         else
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, false>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, false>), grid, dim3(256), 0, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot, cd);
     } else if (ncell <= 1024) {
         const size_t lds = (size_t)pvol * V * sizeof(double);
         if (lds <= 64 * 1024)
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot, cd);
         else
-            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
-    } else if (DIM == 3 && P * P <= 256 && S * S * V <= 2 * SLAB_NR * SLAB_NT) {
+            hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot, cd);
+    } else if (DIM == 3 && P * P <= 256 && S * S * V <= 2 * SLAB_NR * SLAB_NT && !cd.out && !pde_has_xt<PDE>::value) {
         // plane-streaming variant: 3-plane LDS ring (+ 2 planes of per-volume scalars), one workgroup per patch
         constexpr bool CACHE = (MODE == 1) && has_fv_cache<PDE>::value;
         if (CACHE && m != PDE::NV) { set_error("FV Rusanov: the PDE evolves %d variables, got n_real = %d", PDE::NV, m); return -1; }
@@ -667,7 +726,7 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)n_patches), dim3(SLAB_NT), lds, s, Q, P, H, m, V, dt, doh, slot);
     } else if (ncell <= 4096) {
-        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot);
+        hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 4, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot, cd);
     }
     else {
         set_error("FV patch with %ld volumes exceeds the 4096 a workgroup keeps in registers", ncell);
@@ -679,9 +738,10 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
 }
 
 template <int DIM, class PDE>
-static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, const long* slot, hipStream_t s) {
-    if (mode == 0) return fv_dispatch<DIM, PDE, 0>(P, H, m, V, n_patches, Q, dt, h, slot, s);
-    return fv_dispatch<DIM, PDE, 1>(P, H, m, V, n_patches, Q, dt, h, slot, s);
+static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, const long* slot, hipStream_t s,
+                   const FvCellData& cd) {
+    if (mode == 0) return fv_dispatch<DIM, PDE, 0>(P, H, m, V, n_patches, Q, dt, h, slot, s, cd);
+    return fv_dispatch<DIM, PDE, 1>(P, H, m, V, n_patches, Q, dt, h, slot, s, cd);
 }
 
 #ifdef EXA_USER_PDE_HEADER
@@ -689,13 +749,14 @@ static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double*
 // user-PDE side library: the same fused kernel instantiated for exa::UserPDE
 extern "C" int exa_user_nv() { return exa::UserPDE::NV; }
 extern "C" int exa_user_fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                                  double h, const long* slot, void* stream) {
+                                  double h, const long* slot, void* stream, double* out, const double* centre, double t) {
     using namespace exa;
+    const FvCellData cd{out, centre, t, h};
     const int V = n_real + n_aux;
     if (n_real > MAXV || n_real < UserPDE::NV) { set_error("user PDE evolves %d variables; n_real = %d", UserPDE::NV, n_real); return -1; }
     if (n_patches <= 0) return 0;
-    if (dim == 2) return fv_mode<2, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, (hipStream_t)stream);
-    if (dim == 3 && UserPDE::MAXDIM >= 3) return fv_mode<3, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, (hipStream_t)stream);
+    if (dim == 2) return fv_mode<2, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, (hipStream_t)stream, cd);
+    if (dim == 3 && UserPDE::MAXDIM >= 3) return fv_mode<3, UserPDE>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, (hipStream_t)stream, cd);
     set_error("user PDE: no FV kernel for dim %d", dim);
     return -1;
 }
@@ -710,18 +771,19 @@ extern "C" int exa_user_pde_eval(int normal, long n, int stride, const double* Q
 namespace exa {
 #else
 int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
-              double h, const long* slot, hipStream_t s) {
+              double h, const long* slot, hipStream_t s, double* out, const double* centre, double t) {
     const int V = n_real + n_aux;
+    const FvCellData cd{out, centre, t, h};
     if (n_real > MAXV) { set_error("n_real = %d exceeds %d", n_real, MAXV); return -1; }
     if (n_patches <= 0) return 0;
-    if (pde >= 100) return user_fv_launch(pde, mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, s);
+    if (pde >= 100) return user_fv_launch(pde, mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, s, out, centre, t);
     if (dim == 2) {
-        if (pde == 0) return fv_mode<2, EulerRef2D>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
-        if (pde == 1) return fv_mode<2, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
-        if (pde == 2) return fv_mode<2, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
+        if (pde == 0) return fv_mode<2, EulerRef2D>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s, cd);
+        if (pde == 1) return fv_mode<2, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s, cd);
+        if (pde == 2) return fv_mode<2, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s, cd);
     } else if (dim == 3) {
-        if (pde == 1) return fv_mode<3, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
-        if (pde == 2) return fv_mode<3, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s);
+        if (pde == 1) return fv_mode<3, Euler>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s, cd);
+        if (pde == 2) return fv_mode<3, Advection<MAXV>>(mode, P, H, n_real, V, n_patches, Q, dt, h, slot, s, cd);
     }
     set_error("FV Rusanov: no kernel for dim %d, pde %d", dim, pde);
     return -1;

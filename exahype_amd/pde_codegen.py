@@ -41,29 +41,47 @@ class _DevicePrinter(C99CodePrinter):
         return super()._print_Pow(expr)
 
 
+def _arity(fn):
+    import inspect
+    return len([p for p in inspect.signature(fn).parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)])
+
+
 class SympyPDE:
     def __init__(self, n_vars, flux, max_eigenvalue, max_dim=3, name="user", source=None):
         """flux(q, d) -> n_vars expressions, max_eigenvalue(q, d) -> one, in the state symbols q; d = 0-based normal.
         source(q) -> n_vars expressions (optional): the algebraic source S(q) of q_t + div F(q) = S(q) -- the hook the
         reference's harness declares beside flux and maxEigenvalue (`Unit test/correctness_test.cpp:16-23`).  It enters the
-        ADER-DG predictor, the time-averaged volume term and the corrected FV update; the faithful FV mode (the reference's statement list) has no source by construction."""
+        ADER-DG predictor, the time-averaged volume term and the corrected FV update; the faithful FV mode (the reference's statement list) has no source by construction.
+
+        Position and time: the harness declares the terms as flux / maxEigenvalue / sourceTerm(Q, x, h, t, dt, ...)
+        (`Unit test/correctness_test.cpp:16-41`).  Callables that take them -- flux(q, x, t, d), max_eigenvalue(q, x, t, d),
+        source(q, x, t), x = (x0, x1, x2) the volume centre -- generate a term set with HAS_XT; the FV patch kernels hand it the
+        coordinates (`exa_fv_time_step_device_oop`: cell centres and t; the in-place call: patches centred at the origin, t = 0).  The
+        ADER-DG kernels do not carry node coordinates yet: such a term set builds the FV unit only and an ADER-DG plan for it is refused."""
         if not 1 <= n_vars <= 8:
             raise ValueError("n_vars must be 1..8")
         self.n_vars, self.max_dim, self.name = n_vars, max_dim, name
         self.q = self.state(n_vars)
+        self.x = list(sympy.symbols("x0:3", real=True))
+        self.t = sympy.Symbol("t", real=True)
         self.flux_exprs = []
         self.eig_exprs = []
         self.source_exprs = None
+        fx = (lambda q, d: flux(q, self.x, self.t, d)) if _arity(flux) == 4 else flux
+        ex = (lambda q, d: max_eigenvalue(q, self.x, self.t, d)) if _arity(max_eigenvalue) == 4 else max_eigenvalue
         if source is not None:
-            self.source_exprs = [sympy.sympify(e) for e in source(self.q)]
+            self.source_exprs = [sympy.sympify(e) for e in (source(self.q, self.x, self.t) if _arity(source) == 3 else source(self.q))]
             if len(self.source_exprs) != n_vars:
                 raise ValueError("source(q) must return %d expressions" % n_vars)
         for d in range(max_dim):
-            f = [sympy.sympify(e) for e in flux(self.q, d)]
+            f = [sympy.sympify(e) for e in fx(self.q, d)]
             if len(f) != n_vars:
                 raise ValueError("flux(q, %d) must return %d expressions" % (d, n_vars))
             self.flux_exprs.append(f)
-            self.eig_exprs.append(sympy.sympify(max_eigenvalue(self.q, d)))
+            self.eig_exprs.append(sympy.sympify(ex(self.q, d)))
+        xt = set(self.x) | {self.t}
+        every = [e for f in self.flux_exprs for e in f] + self.eig_exprs + (self.source_exprs or [])
+        self.uses_xt = any(e.free_symbols & xt for e in every)
         self._lib = None
         self._id = None
 
@@ -75,6 +93,7 @@ class SympyPDE:
     def _block(self, exprs, targets, indent):
         pr = _DevicePrinter()
         subs = {s: sympy.Symbol("q[%d]" % i) for i, s in enumerate(self.q)}
+        subs.update({s: sympy.Symbol("x[%d]" % i) for i, s in enumerate(self.x)})
         repl, red = sympy.cse([e.subs(subs) for e in exprs], symbols=sympy.numbered_symbols("t_"))
         lines = ["%sconst double %s = %s;" % (indent, pr.doprint(a), pr.doprint(b)) for a, b in repl]
         lines += ["%s%s = %s;" % (indent, t, pr.doprint(e)) for t, e in zip(targets, red)]
@@ -89,8 +108,14 @@ class SympyPDE:
         src_member = ""
         if self.source_exprs is not None:
             src_member = ("    static constexpr bool HAS_SOURCE = true;\n"
-                          "    __device__ static inline void source(const double* q, double* S) {\n%s\n    }\n"
-                          % self._block(self.source_exprs, ["S[%d]" % v for v in range(n)], "        "))
+                          "    __device__ static inline void source%s {\n%s\n    }\n"
+                          % ("_xt(const double* q, const double* x, double t, double* S)" if self.uses_xt else "(const double* q, double* S)",
+                             self._block(self.source_exprs, ["S[%d]" % v for v in range(n)], "        ")))
+            if self.uses_xt:
+                src_member += ("    __device__ static inline void source(const double* q, double* S) { const double x0[3] = {0.0, 0.0, 0.0}; "
+                               "source_xt(q, x0, 0.0, S); }\n")
+        if self.uses_xt:
+            return self._source_xt(flux_cases, eig_cases, src_member)
         return """// generated by exahype_amd/pde_codegen.py from SymPy expressions -- user PDE term set "%s"
 #pragma once
 #include <hip/hip_runtime.h>
@@ -126,6 +151,42 @@ struct UserPDE {
 }  // namespace exa
 """ % (self.name, n, n, self.max_dim, "\n".join(flux_cases), "\n".join(eig_cases), src_member)
 
+    def _source_xt(self, flux_cases, eig_cases, src_member):
+        """Term set whose expressions contain the volume centre x or the time t: the *_xt members carry them (fv_rusanov.hip uses them
+        where HAS_XT is set); the plain members evaluate at x = 0, t = 0 and exist only so that the common interface is complete."""
+        n = self.n_vars
+        return """// generated by exahype_amd/pde_codegen.py from SymPy expressions -- user PDE term set "%s" (terms depend on position / time)
+#pragma once
+#include <hip/hip_runtime.h>
+namespace exa {
+struct UserPDE {
+    static constexpr int NV = %d;
+    static constexpr int NFLUX = %d;
+    static constexpr int NAUX = 1;
+    static constexpr int MAXDIM = %d;
+    static constexpr bool HAS_XT = true;
+    __device__ static inline void aux(const double*, double* a) { a[0] = 0.0; }
+    __device__ static inline void aux_fast(const double*, double* a) { a[0] = 0.0; }
+    __device__ static inline void flux_xt(const double* q, const double* x, double t, int d, double* F) {
+        switch (d) {
+%s
+        default:
+            for (int v = 0; v < NV; v++) F[v] = 0.0;
+        }
+    }
+    __device__ static inline double maxeig_xt(const double* q, const double* x, double t, int d) {
+        switch (d) {
+%s
+        }
+        return 0.0;
+    }
+    __device__ static inline void flux_rt(const double* q, int d, double* F) { const double x0[3] = {0.0, 0.0, 0.0}; flux_xt(q, x0, 0.0, d, F); }
+    __device__ static inline double maxeig(const double* q, int d) { const double x0[3] = {0.0, 0.0, 0.0}; return maxeig_xt(q, x0, 0.0, d); }
+    __device__ static inline double maxeig_fast(const double* q, int d) { return maxeig(q, d); }
+%s};
+}  // namespace exa
+""" % (self.name, n, n, self.max_dim, "\n".join(flux_cases), "\n".join(eig_cases), src_member)
+
     def key(self):
         h = hashlib.sha256(self.source().encode())
         for f in ("dg_inst.hip", "fv_rusanov.hip", "exa_dg_kernels.hpp", "exa_dg_stream.hpp", "exa_dg_reg.hpp", "exa_dg_fused.hpp",
@@ -154,9 +215,11 @@ struct UserPDE {
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         common = [hipcc, "-O3", "-fPIC", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-Wno-unused-function",
                   "-Wno-pass-failed", "-I", CSRC, "-DEXA_PDE_ID=100", '-DEXA_USER_PDE_HEADER="%s"' % hdr]
-        units = [("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2"]), ("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"])]
-        if self.max_dim >= 3:
-            units.append(("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3"]))
+        units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"])]
+        if not self.uses_xt:                                    # (the ADER-DG kernels carry no node coordinates yet)
+            units.append(("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2"]))
+            if self.max_dim >= 3:
+                units.append(("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3"]))
         procs = [(o, subprocess.Popen(common + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(d, o)],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for src, o, extra in units]
         for o, p in procs:

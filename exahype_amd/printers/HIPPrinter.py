@@ -81,6 +81,57 @@ def _rusanov_template(k: KernelBuilder):
     return t
 
 
+def _celldata_template(k: KernelBuilder):
+    """The statement list of `examples/kernel-generator.py:36-45` (the `exahype2::CellData` flavour: input item with halo,
+    halo-less output item, both members of a CellData object; PDE terms that take the volume centre, the volume size, t and dt)
+    rebuilt with the user's names; None if the declarations cannot match."""
+    if len(k.items) != 3 or len(k.directional_items) != 2 or len(k.inputs) != 1 or len(k.functions) != 5 \
+            or len(k.directional_consts) != 1 or len(k.input_types) != 2 or "CellData" not in str(k.input_types[0]):
+        return None
+    data, qout, qin = k.items
+    if k.parents.get(qout) != data or k.parents.get(qin) != data:
+        return None
+    members = [n for n, par in k.parents.items() if par == data and n not in k.items]
+    if len(members) != 4:
+        return None
+    flux_items = [n for n in k.directional_items if k.item_struct[n] == 1]
+    eig_items = [n for n in k.directional_items if k.item_struct[n] == 0]
+    if len(flux_items) != 1 or len(eig_items) != 1:
+        return None
+    (cname, cvals), = k.directional_consts.items()
+    if list(cvals) != list(range(k.dim)):
+        return None
+    t = KernelBuilder(k.dim, k.patch_size, k.halo_size, k.n_real, k.n_aux, k.n_patches)
+    Data = t.item(data, in_type=k.input_types[0])
+    t.const(k.inputs[0], in_type=k.input_types[1])
+    Q = t.item(qout, parent=Data)
+    Qc = t.item(qin, parent=Data)
+    di = {n: t.directional_item(n, struct=(k.item_struct[n] == 1)) for n in k.directional_items}
+    fl, ei = di[flux_items[0]], di[eig_items[0]]
+    # members in the order of the example: dt, t, (the directional constant), cellCentre, cellSize
+    dt = t.const(members[0], parent=Data)
+    tt = t.const(members[1], parent=Data)
+    normal = t.directional_const(cname, tuple(cvals))
+    centre = t.const(members[2], parent=Data)
+    size = t.const(members[3], parent=Data)
+    fn = []
+    for n in k.functions:
+        par = k.parents.get(n)
+        fn.append(t.function(n, parent=par) if par is not None else t.function(n))
+    F, E, M, C, S = fn
+    i, j, kk = t.all_items["i"], t.all_items["j"], t.all_items["k"]
+    patch_size = t.all_items["patch_size"]
+    t.single(Qc[0], Q[0])
+    t.directional(F(Qc[0], C(centre, size, patch_size, {i, j} if k.dim == 2 else {i, j, kk}), S(size, patch_size), tt, dt, normal, fl[0]))
+    t.directional(ei[0], F(Qc[0], C(centre, size, patch_size), S(size, patch_size), tt, dt, normal))
+    t.directional(Qc[0], Qc[0] + 0.5 * (fl[-1] - fl[1]))
+    left = -M(ei[-1], ei[0]) * (Q[0] - Q[-1])
+    right = -M(ei[1], ei[0]) * (Q[0] - Q[1])
+    t.directional(Qc[0], Qc[0] + 0.5 * dt * (left - right), struct=True)
+    t.single(Q[0], Qc[0])
+    return t
+
+
 def _same_statements(a: KernelBuilder, b: KernelBuilder):
     return ([str(x) for x in a.LHS] == [str(x) for x in b.LHS] and [str(x) for x in a.RHS] == [str(x) for x in b.RHS]
             and list(a.directions) == list(b.directions) and list(a.struct_inclusion) == list(b.struct_inclusion))
@@ -94,6 +145,26 @@ class HIPPrinter(CodePrinter):
         self.device = device
         self._impl = None
         self.lowering = None
+        self.cell_data = False
+        if scheme is None:
+            c = None
+            try:
+                c = _celldata_template(k)
+            except Exception:                                   # declarations that resemble the flavour but do not rebuild: not this scheme
+                c = None
+            if c is not None and _same_statements(k, c):
+                # The CellData flavour (examples/kernel-generator.py).  As written the statement list is not an executable scheme (it reads the
+                # OUTPUT item before anything wrote it and takes the wave speed from the flux function); it stands for ExaHyPE 2's batched
+                # Rusanov patch update on a CellData object (`Unit test/correctness_test.cpp:142-155`): QOut = Rusanov update of QIn, out of
+                # place, PDE terms that see the volume centre and the time.  That scheme is what is dispatched; the terms must be named.
+                if pde is None and self._pde_from_bodies(k) is None:
+                    raise UnrecognisedKernel(
+                        "the statement list is the exahype2::CellData flavour of the Rusanov patch update (examples/kernel-generator.py); its "
+                        "PDE terms %s are methods of a Peano solver object -- say which device term set they are with pde= (%s, or a "
+                        "pde_codegen.SympyPDE, whose terms may depend on the volume centre and on t) or give the functions SymPy bodies"
+                        % (list(k.functions[:2]), ", ".join(sorted(PDE_IDS))))
+                self.cell_data = True
+                scheme = "fv-rusanov"
         if scheme is None:
             t = _rusanov_template(k)
             if t is None or not _same_statements(k, t):
@@ -197,6 +268,13 @@ class HIPPrinter(CodePrinter):
                   "// arrays     : u[%d][%s][%d] fp64, AoS (reference layout), updated in place" % (k.n_patches, "][".join([str(N)] * k.dim), k.n_real)]
         else:
             mode = 0 if self.scheme == "fv-rusanov-faithful" else 1
+            if self.cell_data:
+                L += ["// flavour    : exahype2::CellData (examples/kernel-generator.py): %s with halo is read, %s (halo-less) is written; the"
+                      % (k.items[2], k.items[1]),
+                      "//              statement list as written is not executable (reads the output item first, wave speed through the flux",
+                      "//              function): the corrected Rusanov update it stands for is dispatched, out of place",
+                      "// C-ABI      : exa_fv_time_step_device_oop(plan, %s, %s, cellCentre, t, dt, h = cellSize / patch_size, stream)"
+                      % (k.items[2], k.items[1])]
             L += ["// kernel     : fv_rusanov_kernel<%d, mode %d> -- %d statements fused into one launch, one workgroup per patch"
                   % (k.dim, mode, len(k.LHS)),
                   "// C-ABI      : exa_fv_plan_create(dev, %d, %d, %d, %d, %d, %d, %d, %d, &plan); exa_fv_time_step_device(plan, %s, %s, h, stream)"
@@ -253,6 +331,8 @@ class HIPPrinter(CodePrinter):
         """FV: `time_step(Q, dt)` in place on a numpy array (staged) or CUDA tensor (resident).
         ADER-DG: `steps` time steps of u (numpy AoS [cells][nodes][vars]) in place.
         Lowered statement list: `time_step(Q, c0, c1, ...)` with the builder's input constants in declaration order."""
+        if self.cell_data:
+            raise TypeError("the CellData flavour is out of place: use run_cell_data(QIn, dt, t, cell_centre, cell_size)")
         impl = self.compile()
         if self.scheme == "statements":
             for _ in range(steps):
@@ -272,5 +352,14 @@ class HIPPrinter(CodePrinter):
         for _ in range(steps):
             impl.time_step(Q, dt, h)
         return Q
+
+    def run_cell_data(self, QIn, dt, t=0.0, cell_centre=None, cell_size=1.0, out=None):
+        """`time_step(patchData)` of the CellData flavour: QIn [n_patches][(P+2H)^dim][n_real+n_aux] is read, the halo-less QOut
+        [n_patches][P^dim][n_real+n_aux] is returned (numpy in -> numpy out, CUDA tensors stay on the device).  cell_centre:
+        [n_patches][dim] (default: the origin), cell_size: edge length of a patch's cell (volume size h = cell_size / patch_size)."""
+        if not self.cell_data:
+            raise TypeError("this kernel updates its array in place: run(Q, dt)")
+        impl = self.compile()
+        return impl.time_step_oop(QIn, dt, h=float(cell_size) / self.kernel().patch_size, t=t, centres=cell_centre, out=out)
 
     __call__ = run

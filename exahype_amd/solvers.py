@@ -65,6 +65,32 @@ class FVRusanovKernel:
         check(self.lib.exa_fv_time_step_device(self._plan, C.c_void_p(Q.data_ptr()), dt, h, _stream_ptr()))
         return Q
 
+    def time_step_oop(self, QIn, dt, h=1.0, t=0.0, centres=None, out=None):
+        """The `exahype2::CellData` flavour (`examples/kernel-generator.py`): QIn [n_patches][(P+2H)^dim][n_real+n_aux] is only read,
+        the result goes to a separate halo-less array [n_patches][P^dim][n_real+n_aux] (returned; `out` to reuse one).  centres:
+        [n_patches][dim] cell centres (default: the origin) and t reach PDE terms that depend on position and time.  numpy in ->
+        numpy out (staged through the device); CUDA tensors stay on the device."""
+        torch = _torch()
+        host = isinstance(QIn, np.ndarray)
+        dev = torch.device("cuda", self.device)
+        qi = torch.as_tensor(np.ascontiguousarray(QIn), dtype=torch.float64).to(dev) if host else QIn
+        if not (qi.is_cuda and qi.dtype == torch.float64 and qi.is_contiguous() and qi.numel() == self.count):
+            raise ValueError("QIn must hold %d contiguous float64 entries" % self.count)
+        n_out = self.lib.exa_fv_qout_count(self._plan)
+        dim = len(self.shape) - 2
+        P = round((n_out // (self.shape[0] * self.shape[-1])) ** (1.0 / dim))
+        qo = torch.empty((self.shape[0],) + (P,) * dim + (self.shape[-1],), dtype=torch.float64, device=dev) if out is None or host else out
+        if qo.numel() != n_out or not qo.is_contiguous():
+            raise ValueError("out must hold %d contiguous float64 entries" % n_out)
+        cen = None
+        if centres is not None:
+            cen = torch.as_tensor(np.ascontiguousarray(centres), dtype=torch.float64).to(dev) if not isinstance(centres, torch.Tensor) else centres
+            if cen.numel() != self.shape[0] * dim or not cen.is_contiguous():
+                raise ValueError("centres must be [n_patches][dim]")
+        check(self.lib.exa_fv_time_step_device_oop(self._plan, C.c_void_p(qi.data_ptr()), C.c_void_p(qo.data_ptr()),
+                                                   C.c_void_p(cen.data_ptr()) if cen is not None else None, t, dt, h, _stream_ptr()))
+        return qo.cpu().numpy() if host else qo
+
     def __del__(self):
         try:
             self.lib.exa_fv_plan_destroy(self._plan)

@@ -94,6 +94,17 @@ int exa_fv_time_step_device(exa_fv_plan* plan, double* Q_dev, double dt, double 
 int exa_fv_time_step_device_masked(exa_fv_plan* plan, double* Q_dev, const long* slot_dev, double dt, double h,
                                    void* stream);
 
+/* The `exahype2::CellData` flavour of the kernel (`examples/kernel-generator.py:6-45`; `exahype/KernelBuilder.py:217-218`: the output item is
+ * indexed without the halo; `Unit test/correctness_test.cpp:142`: CellData(QIn, cellCentre, cellSize, t, dt, QOut)): QIn_dev
+ * [n_patches][(P+2H)^dim][n_real+n_aux] is only read, QOut_dev [n_patches][P^dim][n_real+n_aux] (exa_fv_qout_count doubles) receives
+ * the updated evolved variables and a copy of the auxiliary ones.  centre_dev: [n_patches][dim] cell centres (NULL: all at the origin)
+ * and t reach PDE term sets that depend on position and time (flux / maxEigenvalue / sourceTerm(Q, x, h, t, dt, ...) of
+ * `Unit test/correctness_test.cpp:16-41`; generated from SymPy expressions by exahype_amd.pde_codegen); the volume centres follow
+ * exahype2::fv::getVolumeCentre: centre - P h / 2 + (index + 1/2) h. */
+int exa_fv_time_step_device_oop(exa_fv_plan* plan, const double* QIn_dev, double* QOut_dev, const double* centre_dev, double t,
+                                double dt, double h, void* stream);
+long exa_fv_qout_count(const exa_fv_plan* plan);
+
 /* ---- ADER-DG cell kernels ---------------------------------------------------- */
 /* N = order + 1 nodes per axis; n_vars must equal the PDE's variable count (5 for
  * both Euler sets, any 1..8 for advection); n_picard < 0 selects N iterations,

@@ -71,6 +71,41 @@ def rusanov_patch_update(KernelBuilder, dim=3, patch_size=6, halo_size=1, n_real
     return kb
 
 
+def cell_data_patch_update(KernelBuilder, dim=2, patch_size=4, halo_size=1, n_real=4, n_aux=0, n_patches=1,
+                           solver="demo::instanceOfSolver"):
+    """The `exahype2::CellData` flavour of the patch update written against exahype_amd's surface with names of its own (the calls the
+    reference's examples/kernel-generator.py makes): a CellData object `cell` with the input array `Uin` (with halo) and the halo-less
+    output `Uout`, PDE terms `F` / `lambdaMax` as methods of a solver object that take the volume centre, the volume size, t and dt."""
+    kb = KernelBuilder(dim=dim, patch_size=patch_size, halo_size=halo_size, n_real=n_real, n_aux=n_aux, n_patches=n_patches)
+    cell = kb.item('cell', in_type='::exahype2::CellData&')
+    kb.const('stopwatch', in_type='::tarch::timing::Measurement&')
+    Uout = kb.item('Uout', parent=cell)
+    Uin = kb.item('Uin', parent=cell)
+    numflux = kb.directional_item('numflux')
+    speed = kb.directional_item('speed', struct=False)
+    tau = kb.const('tau', parent=cell)
+    now = kb.const('now', parent=cell)
+    axis = kb.directional_const('axis', tuple(range(dim)))
+    mid = kb.const('mid', parent=cell)
+    edge = kb.const('edge', parent=cell)
+    F = kb.function('F', parent=solver)
+    lam = kb.function('lambdaMax', parent=solver)
+    mx = kb.function('max')
+    where = kb.function('getVolumeCentre', parent='exahype2::fv::')
+    width = kb.function('getVolumeSize', parent='exahype2::fv::')
+    P = kb.all_items["patch_size"]
+    idx = {kb.all_items["i"], kb.all_items["j"]} if dim == 2 else {kb.all_items["i"], kb.all_items["j"], kb.all_items["k"]}
+    kb.single(Uin[0], Uout[0])
+    kb.directional(F(Uin[0], where(mid, edge, P, idx), width(edge, P), now, tau, axis, numflux[0]))
+    kb.directional(speed[0], F(Uin[0], where(mid, edge, P), width(edge, P), now, tau, axis))
+    kb.directional(Uin[0], Uin[0] + 0.5 * (numflux[-1] - numflux[1]))
+    lo = -mx(speed[-1], speed[0]) * (Uout[0] - Uout[-1])
+    hi = -mx(speed[1], speed[0]) * (Uout[0] - Uout[1])
+    kb.directional(Uin[0], Uin[0] + 0.5 * tau * (lo - hi), struct=True)
+    kb.single(Uout[0], Uin[0])
+    return kb
+
+
 def builder_state(k):
     """The observable state printers read (same dump as tests/golden/make_golden.py)."""
     return dict(

@@ -119,11 +119,25 @@ def test_hip_printer_needs_to_know_the_pde_terms():
         HIPPrinter(k, scheme="aderdg")
 
 
-def test_hip_printer_rejects_reference_cell_data_flavour():
+def test_hip_printer_recognises_the_cell_data_flavour():
+    """examples/kernel-generator.py: recognised (own script: everywhere; the reference's example itself: where its tree is present); the
+    Peano solver's terms are opaque, so a device term set has to be named; the dispatch is the out-of-place corrected Rusanov update."""
     from exahype_amd import KernelBuilder
     from exahype_amd.printers import HIPPrinter, UnrecognisedKernel
-    with pytest.raises(UnrecognisedKernel):
-        HIPPrinter(reference_example("kernel_generator", KernelBuilder))   # Peano CellData flavour: no HIP kernel, says so
+    from tests.ref_examples import cell_data_patch_update, have_reference
+    mine = cell_data_patch_update(KernelBuilder, n_real=4)
+    with pytest.raises(UnrecognisedKernel, match="CellData"):
+        HIPPrinter(mine)
+    hp = HIPPrinter(mine, pde="advection")
+    assert hp.cell_data and hp.scheme == "fv-rusanov" and hp.pde == 2
+    assert "exa_fv_time_step_device_oop(plan, Uin, Uout" in hp.code and "not executable" in hp.code
+    with pytest.raises(TypeError):
+        hp.run(None, 0.1)
+    other = cell_data_patch_update(KernelBuilder, dim=3, patch_size=6, n_real=5, n_aux=2, n_patches=3)
+    assert HIPPrinter(other, pde="euler").cell_data
+    if have_reference():
+        ref = HIPPrinter(reference_example("kernel_generator", KernelBuilder), pde="advection")
+        assert ref.cell_data and "QIn, QOut" in ref.code
 
 
 def test_hip_printer_recognises_the_reference_example_itself():

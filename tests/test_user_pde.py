@@ -316,3 +316,230 @@ def test_source_term_fv_rusanov_vs_numpy():
     assert np.max(np.abs(got - want)) < 1e-12
 
 
+
+
+def euler_gravity(g=(0.3, -0.5, 0.8)):
+    """Compressible Euler with a constant body force: a NONLINEAR five-variable system with a source, S = (0, rho g, m . g)."""
+    from exahype_amd.pde_codegen import SympyPDE
+    base = euler_sympy()
+    q = base.q
+    return SympyPDE(5, flux=lambda qq, d: [e.subs(dict(zip(q, qq))) for e in base.flux_exprs[d]],
+                    max_eigenvalue=lambda qq, d: base.eig_exprs[d].subs(dict(zip(q, qq))),
+                    source=lambda qq: [0, qq[0] * g[0], qq[0] * g[1], qq[0] * g[2], qq[1] * g[0] + qq[2] * g[1] + qq[3] * g[2]],
+                    max_dim=3, name="euler_gravity")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nc", [(6, (2, 2, 1)), (8, (1, 1, 2)), (4, (2, 1, 2))])
+def test_nonlinear_five_variable_source_aderdg_vs_numpy_oracle(N, nc):
+    """Euler + gravity through every 3-D stage-A kernel that carries the source hooks: the register-resident kernel (N = 6; five variables: the
+    same LDS image and lane tables as the built-in Euler, flux of a generated term set dispatched per lane), the matrix-pipe kernel (N = 8) and
+    the LDS-resident kernel (N = 4).  Parity unpinned against the reference (no source fixture there): oracle/aderdg_numpy.py with the same
+    lambdified expressions."""
+    from exahype_amd import solvers as exa
+    from oracle import aderdg_numpy as A
+    from oracle.dg_operators import operators
+    from tests.util import euler_dg_state
+    p = euler_gravity()
+    u = euler_dg_state(tuple(nc) + (N,) * 3, seed=60 + N)
+    dx = [1.0 / c for c in nc]
+    dt = 0.02 * min(dx) / (2 * N - 1)
+    s = exa.AderDgSolver(3, N, nc, pde=p.register(), n_vars=5, dx=dx)
+    s.upload(u)
+    ref = u.copy()
+    for _ in range(2):
+        s.step(dt)
+        ref = A.step(ref, dt, dx, operators(N), NumpyPDE(p))
+    assert np.max(np.abs(s.download() - ref)) / np.max(np.abs(ref)) < 1e-10
+    plain = NumpyPDE(p)
+    del plain.source
+    ref0 = u.copy()
+    for _ in range(2):
+        ref0 = A.step(ref0, dt, dx, operators(N), plain)
+    assert np.max(np.abs(s.download() - ref0)) > 1e-7
+
+
+@pytest.mark.gpu
+def test_source_term_fv_rusanov_3d_plane_streaming_vs_numpy():
+    """3-D patches of 15^3 volumes (the limiter's patch at p = 7: plane-streaming kernel, non-cached path for generated term sets) with a source."""
+    from exahype_amd import solvers as exa
+    from tests.util import euler_dg_state
+    p = euler_gravity()
+    npde = NumpyPDE(p)
+    n_patches, P, H = 2, 15, 1
+    S = P + 2 * H
+    Q = euler_dg_state((n_patches, S, S, S), seed=9)
+    dt, h = 1e-3, 0.05
+    kern = exa.FVRusanovKernel(3, P, H, 5, 0, n_patches, pde=p.register(), mode=exa.FV_RUSANOV)
+    got = np.ascontiguousarray(Q.copy())
+    kern.time_step(got, dt, h)
+    acc = np.zeros((n_patches, P, P, P, 5))
+    core = (slice(None),) + (slice(H, H + P),) * 3
+    for d in range(3):
+        sh = lambda a, s_: np.roll(a, -s_, axis=1 + d)[core]
+        qc, qp, qm = Q[core], sh(Q, 1), sh(Q, -1)
+        lc, lp, lm = npde.maxeig(qc, d), npde.maxeig(qp, d), npde.maxeig(qm, d)
+        Fc, Fp, Fm = npde.flux(qc, d), npde.flux(qp, d), npde.flux(qm, d)
+        acc += 0.5 * (Fc + Fp) - 0.5 * np.maximum(lc, lp)[..., None] * (qp - qc)
+        acc -= 0.5 * (Fm + Fc) - 0.5 * np.maximum(lm, lc)[..., None] * (qc - qm)
+    want = Q.copy()
+    want[core] = Q[core] - dt / h * acc + dt * npde.source(Q[core])
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-12
+
+
+# ---- the exahype2::CellData flavour: out of place, PDE terms that see the volume centre and the time --------------------------------
+class NumpyXtPDE:
+    """SympyPDE with (x, t)-dependent terms, lambdified: flux(q, x, t, d), maxeig(q, x, t, d), source(q, x, t); x[..., 3]."""
+
+    def __init__(self, spde):
+        self.m = spde.n_vars
+        args = list(spde.q) + list(spde.x) + [spde.t]
+        self._f = [sympy.lambdify(args, spde.flux_exprs[d], "numpy") for d in range(spde.max_dim)]
+        self._e = [sympy.lambdify(args, spde.eig_exprs[d], "numpy") for d in range(spde.max_dim)]
+        self._s = sympy.lambdify(args, spde.source_exprs, "numpy") if spde.source_exprs is not None else None
+
+    def _args(self, q, x, t):
+        return [q[..., v] for v in range(self.m)] + [x[..., a] for a in range(3)] + [t]
+
+    def flux(self, q, x, t, d):
+        return np.stack([np.broadcast_to(o, q.shape[:-1]) for o in self._f[d](*self._args(q, x, t))], axis=-1)
+
+    def maxeig(self, q, x, t, d):
+        return np.broadcast_to(self._e[d](*self._args(q, x, t)), q.shape[:-1])
+
+    def source(self, q, x, t):
+        return np.stack([np.broadcast_to(o, q.shape[:-1]) for o in self._s(*self._args(q, x, t))], axis=-1)
+
+
+def variable_coefficient_system(max_dim=2):
+    """Two species advected with a velocity that depends on position and time, and a source that depends on both."""
+    from exahype_amd.pde_codegen import SympyPDE
+    vel = lambda x, t, d: 1 + sympy.Rational(1, 2) * x[d] + sympy.Rational(1, 4) * sympy.sin(t)
+    return SympyPDE(2, flux=lambda q, x, t, d: [vel(x, t, d) * q[0], sympy.Rational(3, 4) * vel(x, t, d) * q[1]],
+                    max_eigenvalue=lambda q, x, t, d: sympy.Abs(vel(x, t, d)),
+                    source=lambda q, x, t: [x[0] * sympy.cos(t) - q[0] * x[1], q[0] - 2 * q[1] + t],
+                    max_dim=max_dim, name="variable_coefficient")
+
+
+def _volume_centres(centres, P, H, h, dim):
+    """[n_patches][S]^dim[3]: exahype2::fv::getVolumeCentre for every volume of the array with halo (halo volumes continue the lattice)."""
+    S = P + 2 * H
+    idx = np.arange(S) - H + 0.5 - 0.5 * P
+    x = np.zeros((len(centres),) + (S,) * dim + (3,))
+    for a in range(dim):
+        sh = [1] * (1 + dim)
+        sh[1 + a] = S
+        x[..., a] = centres[:, a].reshape((-1,) + (1,) * dim) + (idx * h).reshape(sh)
+    return x
+
+
+def test_position_and_time_dependent_terms_generate_an_fv_only_term_set():
+    p = variable_coefficient_system()
+    assert p.uses_xt and "HAS_XT = true" in p.source() and "flux_xt(const double* q, const double* x, double t" in p.source()
+    assert not reaction_advection().uses_xt and "HAS_XT" not in reaction_advection().source()
+
+
+@pytest.mark.gpu
+def test_cell_data_flavour_out_of_place_equals_in_place():
+    """exa_fv_time_step_device_oop with a built-in term set: QOut == the interior the in-place call leaves, bit for bit where both run
+    the same kernel (faithful and corrected mode, the reference's configuration and a 3-D one with auxiliary variables), auxiliary variables
+    copied, QIn untouched."""
+    from exahype_amd import solvers as exa
+    from tests.util import euler_patches, euler_ref2d_patches
+    for dim, P, H, m, aux, pde, mode in ((2, 4, 1, 5, 5, exa.PDE_EULER_REF2D, exa.FV_FAITHFUL), (2, 4, 1, 5, 5, exa.PDE_EULER_REF2D, exa.FV_RUSANOV),
+                                         (3, 6, 1, 5, 2, exa.PDE_EULER, exa.FV_RUSANOV), (3, 15, 1, 5, 0, exa.PDE_EULER, exa.FV_RUSANOV)):
+        n, S, V = 7, P + 2 * H, m + aux
+        Q = euler_ref2d_patches(n, S, V, seed=3) if pde == exa.PDE_EULER_REF2D else euler_patches(n, dim, S, V, seed=4)
+        k = exa.FVRusanovKernel(dim, P, H, m, aux, n, pde=pde, mode=mode)
+        ref = np.ascontiguousarray(Q.copy())
+        k.time_step(ref, 1e-3, 0.05)
+        qin = np.ascontiguousarray(Q.copy())
+        out = k.time_step_oop(qin, 1e-3, 0.05)
+        core = (slice(None),) + (slice(H, H + P),) * dim
+        assert out.shape == (n,) + (P,) * dim + (V,)
+        if P == 15:     # the in-place call of this shape runs the plane-streaming kernel (cached 1/rho, p, c by fast reciprocal / square root)
+            assert np.max(np.abs(out - ref[core])) / np.max(np.abs(ref)) < 1e-13
+        else:
+            assert np.array_equal(out, ref[core])
+        assert np.array_equal(qin, Q) and np.array_equal(out[..., m:], Q[core][..., m:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,P", [(2, 5), (3, 4)])
+def test_cell_data_flavour_position_and_time_dependent_terms_vs_numpy(dim, P):
+    """Rusanov update with terms that depend on the volume centre and on t, against numpy with the SAME lambdified expressions
+    (parity unpinned against the reference: its harness only declares these hooks, `Unit test/correctness_test.cpp:16-41`)."""
+    from exahype_amd import solvers as exa
+    p = variable_coefficient_system(max_dim=dim)
+    npde = NumpyXtPDE(p)
+    n, H = 3, 1
+    S = P + 2 * H
+    rng = np.random.default_rng(17)
+    Q = 1.0 + 0.3 * rng.random((n,) + (S,) * dim + (2,))
+    centres = rng.random((n, dim)) * 2 - 1
+    dt, h, t = 2e-3, 0.07, 0.4
+    kern = exa.FVRusanovKernel(dim, P, H, 2, 0, n, pde=p.register(), mode=exa.FV_RUSANOV)
+    got = kern.time_step_oop(np.ascontiguousarray(Q), dt, h, t=t, centres=centres)
+    x = _volume_centres(centres, P, H, h, dim)
+    core = (slice(None),) + (slice(H, H + P),) * dim
+    acc = np.zeros_like(Q[core])
+    for d in range(dim):
+        sh = lambda a, s_: np.roll(a, -s_, axis=1 + d)[core]
+        qc, qp, qm = Q[core], sh(Q, 1), sh(Q, -1)
+        xc, xp, xm = x[core], sh(x, 1), sh(x, -1)
+        lc, lp, lm = npde.maxeig(qc, xc, t, d), npde.maxeig(qp, xp, t, d), npde.maxeig(qm, xm, t, d)
+        Fc, Fp, Fm = npde.flux(qc, xc, t, d), npde.flux(qp, xp, t, d), npde.flux(qm, xm, t, d)
+        acc += 0.5 * (Fc + Fp) - 0.5 * np.maximum(lc, lp)[..., None] * (qp - qc)
+        acc -= 0.5 * (Fm + Fc) - 0.5 * np.maximum(lm, lc)[..., None] * (qc - qm)
+    want = Q[core] - dt / h * acc + dt * npde.source(Q[core], x[core], t)
+    assert np.max(np.abs(got - want)) < 1e-12
+    # the in-place call of such a term set: patches centred at the origin, t = 0
+    inplace = np.ascontiguousarray(Q.copy())
+    kern.time_step(inplace, dt, h)
+    assert np.array_equal(inplace[core], kern.time_step_oop(np.ascontiguousarray(Q), dt, h))
+
+
+@pytest.mark.gpu
+def test_cell_data_flavour_manufactured_source():
+    """A state that is constant in space with S = (x0 cos t, 1 + x1): the Rusanov update is forward Euler in time, so after K steps
+    q0 = 1 + x0 * sum_k dt cos(t_k), q1 = 2 + K dt (1 + x1) in every volume, to rounding -- position and time reach the term set."""
+    from exahype_amd import solvers as exa
+    from exahype_amd.pde_codegen import SympyPDE
+    p = SympyPDE(2, flux=lambda q, x, t, d: [0 * q[0], 0 * q[1]], max_eigenvalue=lambda q, x, t, d: sympy.Integer(0),     # no flux, no dissipation
+                 source=lambda q, x, t: [x[0] * sympy.cos(t), 1 + x[1]], max_dim=2, name="manufactured_source")
+    n, P, H = 2, 6, 1
+    S = P + 2 * H
+    kern = exa.FVRusanovKernel(2, P, H, 2, 0, n, pde=p.register(), mode=exa.FV_RUSANOV)
+    centres = np.array([[0.5, -1.0], [2.0, 0.25]])
+    h, dt, K = 0.1, 0.05, 6
+    Q = np.zeros((n, S, S, 2))
+    Q[..., 0], Q[..., 1] = 1.0, 2.0
+    x = _volume_centres(centres, P, H, h, 2)
+    core = (slice(None), slice(H, H + P), slice(H, H + P))
+    for k in range(K):
+        out = kern.time_step_oop(np.ascontiguousarray(Q), dt, h, t=k * dt, centres=centres)
+        Q[core] = out
+        # (zero flux and zero wave speed: the halo does not enter)
+    want0 = 1.0 + x[core][..., 0] * sum(dt * np.cos(k * dt) for k in range(K))
+    want1 = 2.0 + K * dt * (1 + x[core][..., 1])
+    assert np.max(np.abs(Q[core][..., 0] - want0)) < 1e-13 and np.max(np.abs(Q[core][..., 1] - want1)) < 1e-13
+
+
+@pytest.mark.gpu
+def test_cell_data_flavour_through_the_printer():
+    """The recognised CellData statement list, dispatched: HIPPrinter(...).run_cell_data == FVRusanovKernel.time_step_oop."""
+    from exahype_amd import KernelBuilder, solvers as exa
+    from exahype_amd.printers import HIPPrinter
+    from tests.ref_examples import cell_data_patch_update
+    p = variable_coefficient_system()
+    kb = cell_data_patch_update(KernelBuilder, dim=2, patch_size=5, halo_size=1, n_real=2, n_aux=0, n_patches=3)
+    hp = HIPPrinter(kb, pde=p)
+    rng = np.random.default_rng(23)
+    Q = 1.0 + 0.3 * rng.random((3, 7, 7, 2))
+    centres = rng.random((3, 2))
+    out = hp.run_cell_data(np.ascontiguousarray(Q), 1e-3, t=0.3, cell_centre=centres, cell_size=0.5)
+    kern = exa.FVRusanovKernel(2, 5, 1, 2, 0, 3, pde=p.register(), mode=exa.FV_RUSANOV)
+    assert np.array_equal(out, kern.time_step_oop(np.ascontiguousarray(Q), 1e-3, 0.1, t=0.3, centres=centres))
+    from exahype_amd._lib import ExaHypeHipError
+    with pytest.raises(ExaHypeHipError):                         # ADER-DG kernels carry no node coordinates yet: refused, not ignored
+        exa.AderDgSolver(2, 3, (2, 2), pde=p.register(), n_vars=2)
