@@ -54,6 +54,17 @@ template <class PDE> __device__ inline void fv_source(const double* q, const dou
     if constexpr (pde_has_xt<PDE>::value) PDE::source_xt(q, x, t, S);
     else PDE::source(q, S);
 }
+// Optional: `static constexpr bool HAS_NCP = true` with ncp(q, dq, d, out) (HAS_XT: ncp_xt(q, dq, x, t, d, out)) = B_d(q) dq, the
+// non-conservative product of q_t + div F(q) + B(q) . grad q = S(q) -- the `ncp` slot of the kernel the reference's harness targets
+// (`Unit test/correctness_test.cpp:145-155`: <Flux, ncp, Source, Eigen>).  Corrected Rusanov mode only: across a face the jump term
+// D = B_d((q_L + q_R) / 2) (q_R - q_L) (straight path, midpoint) goes half to either side, as ExaHyPE 2's FV Rusanov solver does.
+template <class P, class = void> struct pde_has_ncp : std::false_type {};
+template <class P> struct pde_has_ncp<P, std::void_t<decltype(P::HAS_NCP)>> : std::bool_constant<P::HAS_NCP> {};
+template <class PDE> __device__ inline void fv_ncp(const double* q, const double* dq, const double* x, double t, int d, double* out) {
+    if constexpr (pde_has_xt<PDE>::value) PDE::ncp_xt(q, dq, x, t, d, out);
+    else PDE::ncp(q, dq, d, out);
+}
+
 // What the `exahype2::CellData` flavour of the kernel adds to (Q, dt) (`exahype/KernelBuilder.py:217-218`, `Unit test/correctness_test.cpp:142`):
 // a separate, halo-less output array, the patch centres and the time.  All null / zero for the in-place call.
 struct FvCellData {
@@ -253,6 +264,25 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
 #pragma unroll
                 for (int v = 0; v < MAXV; v++)
                     if (v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qmp[v]);
+                if constexpr (pde_has_ncp<PDE>::value) {             // + (D_{c,c+1} + D_{c-1,c}) / 2, each at the face's mean state (and mid point)
+                    double qa[MAXV], dq[MAXV], D[MAXV];
+                    [[maybe_unused]] double xf[3];
+#pragma unroll
+                    for (int side = 0; side < 2; side++) {
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++) {
+                            const double qo = side == 0 ? qpp[v] : qmp[v];
+                            qa[v] = 0.5 * (qc[v] + qo);
+                            dq[v] = side == 0 ? qo - qc[v] : qc[v] - qo;
+                            D[v] = 0.0;
+                        }
+                        if constexpr (pde_has_xt<PDE>::value) shifted(d, side == 0 ? 0.5 : -0.5, xf);
+                        fv_ncp<PDE>(qa, dq, xf, cd.t, d, D);
+#pragma unroll
+                        for (int v = 0; v < MAXV; v++)
+                            if (v < m) acc[v] += 0.5 * D[v];
+                    }
+                }
             }
 #pragma unroll
             for (int v = 0; v < MAXV; v++) nv[k][v] = qc[v] - dt_over_h * acc[v];
@@ -714,7 +744,7 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, true>), dim3((unsigned)n_patches), dim3(1024), lds, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot, cd);
         else
             hipLaunchKernelGGL((fv_rusanov_kernel<DIM, PDE, MODE, 1, 1024, false>), dim3((unsigned)n_patches), dim3(1024), 0, s, Q, P, H, m, V, dt, doh, n_patches, 1, slot, cd);
-    } else if (DIM == 3 && P * P <= 256 && S * S * V <= 2 * SLAB_NR * SLAB_NT && !cd.out && !pde_has_xt<PDE>::value) {
+    } else if (DIM == 3 && P * P <= 256 && S * S * V <= 2 * SLAB_NR * SLAB_NT && !cd.out && !pde_has_xt<PDE>::value && !pde_has_ncp<PDE>::value) {
         // plane-streaming variant: 3-plane LDS ring (+ 2 planes of per-volume scalars), one workgroup per patch
         constexpr bool CACHE = (MODE == 1) && has_fv_cache<PDE>::value;
         if (CACHE && m != PDE::NV) { set_error("FV Rusanov: the PDE evolves %d variables, got n_real = %d", PDE::NV, m); return -1; }

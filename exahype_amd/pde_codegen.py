@@ -47,11 +47,16 @@ def _arity(fn):
 
 
 class SympyPDE:
-    def __init__(self, n_vars, flux, max_eigenvalue, max_dim=3, name="user", source=None):
+    def __init__(self, n_vars, flux, max_eigenvalue, max_dim=3, name="user", source=None, ncp=None):
         """flux(q, d) -> n_vars expressions, max_eigenvalue(q, d) -> one, in the state symbols q; d = 0-based normal.
         source(q) -> n_vars expressions (optional): the algebraic source S(q) of q_t + div F(q) = S(q) -- the hook the
         reference's harness declares beside flux and maxEigenvalue (`Unit test/correctness_test.cpp:16-23`).  It enters the
         ADER-DG predictor, the time-averaged volume term and the corrected FV update; the faithful FV mode (the reference's statement list) has no source by construction.
+
+        ncp(q, dq, d) (or ncp(q, dq, x, t, d)) -> n_vars expressions (optional): the non-conservative product B_d(q) dq of
+        q_t + div F(q) + B(q) . grad q = S(q), dq = the jump (or gradient) of q along direction d -- the `ncp` slot of the kernel the
+        harness targets (`Unit test/correctness_test.cpp:145-155`).  Built into the corrected FV Rusanov update (path-conservative jump
+        term, half to either side of a face); the ADER-DG kernels have no such term yet, so a term set with an ncp builds the FV unit only.
 
         Position and time: the harness declares the terms as flux / maxEigenvalue / sourceTerm(Q, x, h, t, dt, ...)
         (`Unit test/correctness_test.cpp:16-41`).  Callables that take them -- flux(q, x, t, d), max_eigenvalue(q, x, t, d),
@@ -79,8 +84,18 @@ class SympyPDE:
                 raise ValueError("flux(q, %d) must return %d expressions" % (d, n_vars))
             self.flux_exprs.append(f)
             self.eig_exprs.append(sympy.sympify(ex(self.q, d)))
+        self.dq = list(sympy.symbols("dq0:%d" % n_vars, real=True))
+        self.ncp_exprs = None
+        if ncp is not None:
+            nx = (lambda q, dq, d: ncp(q, dq, self.x, self.t, d)) if _arity(ncp) == 5 else ncp
+            self.ncp_exprs = []
+            for d in range(max_dim):
+                e = [sympy.sympify(v) for v in nx(self.q, self.dq, d)]
+                if len(e) != n_vars:
+                    raise ValueError("ncp(q, dq, %d) must return %d expressions" % (d, n_vars))
+                self.ncp_exprs.append(e)
         xt = set(self.x) | {self.t}
-        every = [e for f in self.flux_exprs for e in f] + self.eig_exprs + (self.source_exprs or [])
+        every = [e for f in self.flux_exprs for e in f] + self.eig_exprs + (self.source_exprs or []) + [e for f in (self.ncp_exprs or []) for e in f]
         self.uses_xt = any(e.free_symbols & xt for e in every)
         self._lib = None
         self._id = None
@@ -94,6 +109,7 @@ class SympyPDE:
         pr = _DevicePrinter()
         subs = {s: sympy.Symbol("q[%d]" % i) for i, s in enumerate(self.q)}
         subs.update({s: sympy.Symbol("x[%d]" % i) for i, s in enumerate(self.x)})
+        subs.update({s: sympy.Symbol("dq[%d]" % i) for i, s in enumerate(self.dq)})
         repl, red = sympy.cse([e.subs(subs) for e in exprs], symbols=sympy.numbered_symbols("t_"))
         lines = ["%sconst double %s = %s;" % (indent, pr.doprint(a), pr.doprint(b)) for a, b in repl]
         lines += ["%s%s = %s;" % (indent, t, pr.doprint(e)) for t, e in zip(targets, red)]
@@ -114,6 +130,13 @@ class SympyPDE:
             if self.uses_xt:
                 src_member += ("    __device__ static inline void source(const double* q, double* S) { const double x0[3] = {0.0, 0.0, 0.0}; "
                                "source_xt(q, x0, 0.0, S); }\n")
+        if self.ncp_exprs is not None:
+            cases = ["        case %d: {\n%s\n        } break;" % (d, self._block(self.ncp_exprs[d], ["out[%d]" % v for v in range(n)], "            "))
+                     for d in range(self.max_dim)]
+            sig = "ncp_xt(const double* q, const double* dq, const double* x, double t, int d, double* out)" if self.uses_xt \
+                else "ncp(const double* q, const double* dq, int d, double* out)"
+            src_member += ("    static constexpr bool HAS_NCP = true;\n    __device__ static inline void %s {\n        switch (d) {\n%s\n"
+                           "        default:\n            for (int v = 0; v < NV; v++) out[v] = 0.0;\n        }\n    }\n" % (sig, "\n".join(cases)))
         if self.uses_xt:
             return self._source_xt(flux_cases, eig_cases, src_member)
         return """// generated by exahype_amd/pde_codegen.py from SymPy expressions -- user PDE term set "%s"
@@ -216,7 +239,7 @@ struct UserPDE {
         common = [hipcc, "-O3", "-fPIC", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-Wno-unused-function",
                   "-Wno-pass-failed", "-I", CSRC, "-DEXA_PDE_ID=100", '-DEXA_USER_PDE_HEADER="%s"' % hdr]
         units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"])]
-        if not self.uses_xt:                                    # (the ADER-DG kernels carry no node coordinates yet)
+        if not self.uses_xt and self.ncp_exprs is None:         # (the ADER-DG kernels carry no node coordinates and no ncp term yet)
             units.append(("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2"]))
             if self.max_dim >= 3:
                 units.append(("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3"]))
