@@ -199,6 +199,8 @@ class HaloExchange:
                 self.ghost[d * 2 + 1], self.ghost[d * 2 + 0] = self._ghost_pair[d][0], self._ghost_pair[d][1]
 
     def pack(self, trace):
+        """CPU rehearsals only (tests/test_partition_halo.py: gloo, plain tensors).  The product path packs on the device with
+        exa_dg_pack_face (AderDgSolver._pack_faces)."""
         for d in range(self.part.dim):
             if not self.part.partitioned(d):
                 continue

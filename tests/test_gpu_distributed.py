@@ -221,3 +221,51 @@ def test_sharded_limited_step_over_rccl_send_recv_to_self(tmp_path):
     """cfg 4's order (p = 7, 17^3 FV patches) with both limiter exchanges (troubled flags, subcell layers) and the trace exchange over RCCL
     send/recv to self."""
     _run_ranks(tmp_path, RCCL_SELF_LIM_WORKER % dict(root=ROOT, N=8, nc=(2, 1, 2)), 1)
+
+
+@pytest.mark.parametrize("N,nc", [(3, (2, 2, 2)), (6, (2, 1, 2))])
+def test_full_2x2x2_layout_eight_shards_in_one_process(N, nc):
+    """configs[3]'s process grid at kernel level: EIGHT shards of a periodic grid -- all three directions partitioned, every shard with
+    ghosts on all six faces -- each with its own plan, boundary shell, packed faces (exa_dg_pack_face), ghost buffers and stage B on
+    ghosts; the exchange itself is a device copy between the shards' buffers (eight processes cannot share the box's one GPU: at most six
+    may, and RCCL needs a GPU per rank; the transport is covered by the gloo runs above, by tests/test_partition_halo.py with world 8
+    and by the RCCL-to-self test).  The result must equal the oracle's step of the whole 2 nc grid."""
+    import numpy as np
+    import torch
+    from exahype_amd import solvers as exa
+    import oracle
+    from oracle.dg_operators import operators
+    from tests.util import euler_dg_state
+    dim = 3
+    G = tuple(2 * c for c in nc)
+    u = euler_dg_state(G + (N,) * dim, seed=88)
+    dx = [1.0 / g for g in G]
+    dt = 0.02 * min(dx) / (2 * N - 1)
+    parts = [exa.CartesianPartition(8, r, dim) for r in range(8)]
+    assert parts[0].pdims == [2, 2, 2]
+    shards = [exa.AderDgSolver(dim, N, nc, dx=dx, part=p, backend_is_gloo=True) for p in parts]
+    sl = [tuple(slice(p.coords[a] * nc[a], (p.coords[a] + 1) * nc[a]) for a in range(3)) for p in parts]
+    for s, w in zip(shards, sl):
+        s.upload(u[w])
+    ref = u.reshape(-1).copy()
+    for _ in range(2):
+        for s in shards:                                          # stage A on the boundary shell, faces packed
+            for lo, hi in s.shell:
+                s.predictor_volume(dt, lo, hi)
+            s._pack_faces()
+        for r, s in enumerate(shards):                            # "exchange": my ghost pair of direction d = the peer's send pair
+            for d in range(3):
+                peer = parts[r].neighbour(d, +1)
+                assert peer == parts[r].neighbour(d, -1) and peer != r
+                s.halo._ghost_pair[d].copy_(shards[peer].halo._send_pair[d])
+        for s in shards:                                          # interior cells, then Riemann + corrector on the ghosts
+            lo, hi = s.interior
+            if all(h > l for l, h in zip(lo, hi)):
+                s.predictor_volume(dt, lo, hi)
+            s.riemann_corrector(dt)
+        ref = oracle.aderdg_step(ref, dt, dx, operators(N), dim, N, 5, oracle.PDE_EULER, N, G)
+    torch.cuda.synchronize()
+    want = ref.reshape(u.shape)
+    for s, w in zip(shards, sl):
+        err = np.max(np.abs(s.download() - want[w])) / np.max(np.abs(want))
+        assert err < 1e-10, err
