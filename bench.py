@@ -347,7 +347,7 @@ def run_cfg1(a, torch, exa, local):
     tk = e0.elapsed_time(e1) / steps * 1e-3
     dof = nc[0] * nc[1] * N * N * 5
     b_alg = 8 * 5 * (2 * N ** 2 + 8 * 2 * N) * nc[0] * nc[1]            # 3 840 B per cell
-    traffic, src = read_traffic("r02_traffic_cfg1.json")
+    traffic, src = read_traffic("traffic_cfg1.json")
     out = {"metric": "DoF-updates/sec, 2D Euler p=3 volume+Riemann+corrector (single stage), 1 MI355X", "value": dof * steps / el,
            "unit": "DoF-updates/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -390,7 +390,7 @@ def run_cfg4(a, torch, exa, local):
     ta = sum(e0.elapsed_time(e1) for e0, e1 in s.stage_a_events) / steps * 1e-3
     work = s.work()
     dof = n ** 3 * N ** 3 * 5
-    traffic, src = read_traffic("r02_traffic_cfg4.json", cells=n)
+    traffic, src = read_traffic("traffic_cfg4.json", cells=n, kernel=s.stage_a_kernel_name())
     out = {"metric": "DoF-updates/sec, 3D Euler p=7 ADER-DG + FV subcell limiter, 1 MI355X", "value": dof * steps / el, "unit": "DoF-updates/s",
            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -398,7 +398,7 @@ def run_cfg4(a, torch, exa, local):
                                   "volume + Riemann + corrector, FV subcell limiter (15^3 patches) on a Bernoulli(0.05) troubled mask" % n,
                       "cells_per_gpu": n ** 3, "order": 7, "n_vars": 5, "dt": dt, "troubled_cells": int(cnt)},
            "finite": bool(torch.isfinite(s.u).all().item()),
-           "roofline": {"kernel": "dg_stage_a_stream_kernel<8,Euler>", "bound": "fp64-valu", "bound_basis": "algorithmic flops (SURVEY.md 8(d))",
+           "roofline": {"kernel": s.stage_a_kernel_name(), "bound": "fp64-valu", "bound_basis": "algorithmic flops (SURVEY.md 8(d))",
                         "hbm_measured_gbs": (traffic / ta / 1e9) if traffic else None, "achieved": work["flop_a"] / ta / 1e12,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": work["flop_a"] / ta / 1e12 / FP64_PEAK_TFLOPS,
                         "frac_of_measured_fma_loop": work["flop_a"] / ta / 1e12 / FP64_MEASURED_TFLOPS, "traffic": traffic,
@@ -439,7 +439,7 @@ def run_fv_ref(a, torch, exa, local):
     Q = Qs
     vols = n * P * P
     b_alg = vols * (8 * V * (S / P) ** 2 + 8 * m)                       # patch + halo read once, n_real written once (220 B per volume)
-    traffic, src = read_traffic("r02_traffic_fv_ref.json")
+    traffic, src = read_traffic("traffic_fv_ref.json")
     out = {"metric": "DoF-updates/sec, FV Rusanov patch update (reference configuration 2D P=4 H=1 5+5 vars), 1 MI355X",
            "value": vols * m * steps / el, "unit": "DoF-updates/s", "volume_updates_per_s": vols * steps / el, "n_gpus": 1, "steps": steps,
            "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",

@@ -33,9 +33,10 @@ PY
 }
 echo "== bench lines"; 
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; tail -c 600 $OUT/bench_cfg2.json; echo
+python3 bench.py --gpus 1 --self-exchange --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg2_self_exchange.json 2> $OUT/bench_cfg2_self_exchange.err; tail -c 400 $OUT/bench_cfg2_self_exchange.json; echo
 for cfg in cfg1 cfg4 fv-ref; do python3 bench.py --config $cfg --steps 10 --warmup 3 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; tail -c 300 $OUT/bench_$cfg.json; echo; done
 echo "== kernel trace of the headline command"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace_cfg2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/trace_cfg2.log 2>&1
 find $OUT/trace_cfg2 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_cfg2.csv \;
 head -8 $OUT/kernel_stats_cfg2.csv
 for cfg in cfg1 cfg4 fv-ref; do
@@ -44,9 +45,9 @@ for cfg in cfg1 cfg4 fv-ref; do
   head -5 $OUT/kernel_stats_$cfg.csv
 done
 echo "== traffic"
-traffic cfg2 dg_stage_a_kernel '{"cells": 128, "order": 5, "algorithmic_bytes_per_launch": 72477573120.0}' -- --steps 2 --warmup 1
+traffic cfg2 dg_stage_a_reg_kernel '{"kernel": "dg_stage_a_reg_kernel<6, exa::Euler, 2>", "cells": 128, "order": 5, "algorithmic_bytes_per_launch": 72477573120.0}' -- --steps 2 --warmup 1 --no-other-configs
 traffic cfg1 dg_fused_single_kernel '{"algorithmic_bytes_per_launch": 1006632960.0}' -- --config cfg1 --steps 5 --warmup 2
-traffic cfg4 dg_stage_a_stream_kernel '{"cells": 64}' -- --config cfg4 --steps 2 --warmup 1
+traffic cfg4 dg_stage_a_m8_kernel '{"kernel": "dg_stage_a_m8_kernel<exa::Euler>", "cells": 64}' -- --config cfg4 --steps 2 --warmup 1
 traffic fv_ref fv_rusanov_kernel '{"algorithmic_bytes_per_launch": 3690987520.0}' -- --config fv-ref --steps 5 --warmup 2
 # the limiter's FV patch kernel (15^3 patches) inside cfg4
 python3 - "$OUT" <<'PY'
@@ -60,5 +61,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 xs.append(float(r["Counter_Value"]))
     print("fv_rusanov_slab_kernel in cfg4:", c, "n=%d mean=%.6g KiB" % (len(xs), sum(xs) / max(len(xs), 1)))
 PY
+echo "== SQ counters of stage A (48^3 cells)"
+scripts/pmc_stage_a.sh ${TAG}sq 48 5 > $OUT/pmc_stage_a_48cubed.txt 2>&1 || tail -5 $OUT/pmc_stage_a_48cubed.txt
+python3 scripts/stage_a_pmc_json.py "$OUT/pmc_stage_a_48cubed.txt" "$OUT/stage_a_pmc.json" 48 5
 rm -rf $OUT/trace_*/ $OUT/pmc_*/          # keep the summaries, not the raw traces (size)
 ls $OUT
