@@ -210,19 +210,18 @@ struct Euler {
     static constexpr int NFVAUX = 3;
     __device__ static inline void fv_aux(const double* q, double* a) {
         const double irho = fast_rcp(q[0]);
-        const double p = (GAMMA - 1) * (q[4] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+        const double p = (GAMMA - 1) * fma(-0.5 * irho, fma(q[3], q[3], fma(q[2], q[2], q[1] * q[1])), q[4]);
         a[0] = irho;
         a[1] = p;
         a[2] = fast_sqrt(GAMMA * fabs(p) * fabs(irho));
     }
     template <int D> __device__ static inline void flux_fv(const double* q, const double* a, double* F) {
-        const double coeff = a[0] * q[D + 1];
-        F[0] = coeff * q[0];
-        F[1] = coeff * q[1];
-        F[2] = coeff * q[2];
-        F[3] = coeff * q[3];
-        F[4] = coeff * q[4] + coeff * a[1];
-        F[D + 1] += a[1];
+        const double coeff = a[0] * q[D + 1];                 // explicit fma: the FV unit is compiled without contraction (faithful mode)
+        F[0] = q[D + 1];
+        F[1] = D == 0 ? fma(coeff, q[1], a[1]) : coeff * q[1];
+        F[2] = D == 1 ? fma(coeff, q[2], a[1]) : coeff * q[2];
+        F[3] = D == 2 ? fma(coeff, q[3], a[1]) : coeff * q[3];
+        F[4] = coeff * (q[4] + a[1]);
     }
     template <int D> __device__ static inline double maxeig_fv(const double* q, const double* a) {
         return fabs(q[D + 1] * a[0]) + a[2];              // max(|u_n - c|, |u_n + c|) = |u_n| + c

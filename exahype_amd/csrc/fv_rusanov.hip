@@ -79,6 +79,24 @@ struct FvCellData {
 // SHAPE: compile-time (patch_size, halo_size, n_real, n_real + n_aux), or all zero for run-time values.  The reference's
 // own configuration (4, 1, 5, 10) is built specialised: the variable masks and the 64-bit index arithmetic fold away
 // (a wave executed ~1 030 VALU instructions in the generic build; the arithmetic and its order are the same).
+#ifndef EXA_FV_STORE
+#define EXA_FV_STORE 1
+#endif
+__device__ inline void fv_row_store(v2d val, v2d* at) {
+#if EXA_FV_STORE == 0
+    *at = val;
+#elif EXA_FV_STORE == 1
+    __builtin_nontemporal_store(val, at);
+#elif EXA_FV_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(at), "v"(val) : "memory");
+#elif EXA_FV_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(at), "v"(val) : "memory");
+#elif EXA_FV_STORE == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(at), "v"(val) : "memory");
+#elif EXA_FV_STORE == 5
+    asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(at), "v"(val) : "memory");
+#endif
+}
 template <int TP, int TH, int TM, int TV> struct FvShape {
     static constexpr int P = TP, H = TH, M = TM, V = TV;
 };
@@ -118,7 +136,11 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
 #pragma unroll
         for (int r = 0; r < HRS; r++) {
             const int xx = (int)threadIdx.x + r * NT;
+#ifdef EXA_FV_NTLOAD
+            hold[r] = __builtin_nontemporal_load(s2 + (xx < npair ? xx : npair - 1));
+#else
             hold[r] = s2[xx < npair ? xx : npair - 1];
+#endif
         }
     };
     if constexpr (PERSIST) request(blockIdx.x);
@@ -168,6 +190,16 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
         const int id = (CPT == 1) ? (int)threadIdx.x - pl * ncell : (int)threadIdx.x + k * NT;
         cidx[k] = -1;
         if (!live || id >= ncell) continue;
+#ifdef EXA_FV_ABL_NOCOMPUTE
+        {
+            int co[3];
+            if constexpr (DIM == 3) { co[0] = id / (P * P) + H; co[1] = (id / P) % P + H; co[2] = id % P + H; }
+            else { co[0] = id / P + H; co[1] = id % P + H; co[2] = 0; }
+            cidx[k] = co[0] * st[0] + co[1] * st[1] + co[2] * st[2];
+            for (int v = 0; v < MAXV; v++) nv[k][v] = v < m ? Qp[cidx[k] * V + v] : 0.0;
+            continue;
+        }
+#endif
         int co[3];
         if constexpr (DIM == 3) { co[0] = id / (P * P) + H; co[1] = (id / P) % P + H; co[2] = id % P + H; }
         else { co[0] = id / P + H; co[1] = id % P + H; co[2] = 0; }
@@ -297,7 +329,13 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             }
         }
     }
-    if (cd.out) {
+    // staged + (auxiliary variables present or out of place), V even, arrays 16-byte aligned: results go into the LDS copy first, then whole
+    // interior rows (P*V contiguous doubles) stream out with coalesced 16-byte stores -- back into Q, or packed densely into QOut
+    bool rows = false;
+    if constexpr (STAGE)
+        rows = ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (V % 2 == 0) &&
+               (cd.out ? (reinterpret_cast<unsigned long long>(cd.out) & 15) == 0 : V > m);
+    if (cd.out && !rows) {
         // out of place (the CellData flavour): QOut is halo-less, [patch][volume][n_real + n_aux] -- thread order is volume order, every
         // thread writes the V contiguous doubles of its volume (evolved variables updated, auxiliary ones copied): fully coalesced
 #pragma unroll
@@ -315,12 +353,9 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
     }
     // every read of this patch is done (loads feed the values above) before any write
     __syncthreads();
-    bool rows = false;
-    if constexpr (STAGE) {
-        // auxiliary variables present (V even, rows 16-byte aligned): results go into the LDS copy first, then
-        // whole interior rows (P*V contiguous doubles) stream back with coalesced 16-byte stores
-        rows = ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (V % 2 == 0) && (V > m);
-    }
+#ifdef EXA_FV_ABL_NOWRITE
+    if (rows) { if (nv[0][0] == 1.2345e-300) Q[0] = 0.0; rows = false; if constexpr (PERSIST) __syncthreads(); continue; }
+#endif
     if (rows) {
         double* Ql = fv_lds + (long)(live ? pl : 0) * vol * V;
 #pragma unroll
@@ -336,9 +371,41 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
         const int rows_pp = (DIM == 3) ? P * P : P;                  // interior rows per patch
         const int r2 = P * V / 2;                                    // double2 per row
         double* dst = Q + first * vol * V;
+        if (cd.out) {                                                // QOut: [patch][interior row][P*V], dense
+            v2d* od = reinterpret_cast<v2d*>(cd.out + first * ncell * V);
+            for (long e = threadIdx.x; e < npatch * rows_pp * r2; e += NT) {
+                const long row = e / r2;
+                const int x = (int)(e - row * r2);
+                const long pp = row / rows_pp;
+                const int rr = (int)(row - pp * rows_pp);
+                const long o = pp * vol * V + ((DIM == 3) ? ((long)(rr / P + H) * S * S + (long)(rr % P + H) * S + H) : ((long)(rr + H) * S + H)) * V;
+                __builtin_nontemporal_store(reinterpret_cast<const v2d*>(fv_lds + o)[x], od + e);
+            }
+            if constexpr (PERSIST) __syncthreads();
+            continue;
+        }
         // (tried in r2: rows j in [H, P+H) with ALL k as one contiguous block per patch, the k-halo volumes rewriting their old
         // values -- no partial lines but +50 % bytes written at P = 4: 1.07 ms against 1.00 ms; the kernel moves its ACTUAL
         // 4.5 GB at 4.5 TB/s either way)
+#ifdef EXA_FV_WALIGN
+        // whole EXA_FV_WALIGN-byte units: a row's span is widened to the unit boundaries either side, the halo bytes in those units
+        // rewrite their own (unchanged) values from the LDS copy -- no partially written unit reaches the memory controller
+        constexpr int AL = EXA_FV_WALIGN / 8;
+        const int mis = (int)((reinterpret_cast<unsigned long long>(dst) >> 3) & (AL - 1));
+        const int slots = (P * V + 2 * (AL - 1) + 1) / 2;
+        for (long e = threadIdx.x; e < npatch * rows_pp * slots; e += NT) {
+            const long row = e / slots;
+            const int x = (int)(e - row * slots);
+            const long pp = row / rows_pp;
+            const int rr = (int)(row - pp * rows_pp);
+            const long o = pp * vol * V + ((DIM == 3) ? ((long)(rr / P + H) * S * S + (long)(rr % P + H) * S + H) : ((long)(rr + H) * S + H)) * V;
+            long lo = ((o + mis) & ~(long)(AL - 1)) - mis, hi = ((o + P * V + mis + AL - 1) & ~(long)(AL - 1)) - mis;
+            lo = lo < pp * vol * V ? pp * vol * V : lo;
+            hi = hi > (pp + 1) * vol * V ? (pp + 1) * vol * V : hi;
+            const long at = lo + 2 * x;
+            if (at < hi) __builtin_nontemporal_store(*reinterpret_cast<const v2d*>(fv_lds + at), reinterpret_cast<v2d*>(dst + at));
+        }
+#else
         for (long e = threadIdx.x; e < npatch * rows_pp * r2; e += NT) {
             const long row = e / r2;
             const int x = (int)(e - row * r2);
@@ -346,8 +413,9 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             const int rr = (int)(row - pp * rows_pp);
             const long o = pp * vol * V + ((DIM == 3) ? ((long)(rr / P + H) * S * S + (long)(rr % P + H) * S + H) : ((long)(rr + H) * S + H)) * V;
             // streaming store: the rows start at 80-byte offsets, i.e. partial cache lines -- do not allocate them in L2
-            __builtin_nontemporal_store(reinterpret_cast<const v2d*>(fv_lds + o)[x], reinterpret_cast<v2d*>(dst + o) + x);
+            fv_row_store(reinterpret_cast<const v2d*>(fv_lds + o)[x], reinterpret_cast<v2d*>(dst + o) + x);
         }
+#endif
     } else {
 #pragma unroll
         for (int k = 0; k < CPT; k++) {
@@ -384,35 +452,47 @@ template <class P> struct has_fv_cache<P, std::void_t<decltype(P::NFVAUX)>> : st
 
 constexpr int SLAB_NT = 256;
 constexpr int SLAB_NR = 4;          // double2 per thread that hold a plane in flight (<= 2048 doubles per plane)
+// ring slot: an even number of doubles with one to spare -- a plane sits in its slot at the parity of its HBM address, so that every
+// 16-byte aligned pair of HBM is a 16-byte aligned pair of LDS (ds_write_b128 / ds_read_b128 for the landing and the row blocks)
+__host__ __device__ constexpr int slab_slot(int S, int V) { return (S * S * V + 2) & ~1; }
 __host__ __device__ constexpr size_t slab_lds_bytes(int S, int V, bool cache) {
-    return ((size_t)3 * S * S * V + (cache ? (size_t)2 * S * S * 3 : 0)) * sizeof(double);
+    return ((size_t)3 * slab_slot(S, V) + (cache ? (size_t)2 * S * S * 3 : 0)) * sizeof(double);
 }
 
-template <class PDE, int MODE, bool CACHE>
+// FITNV: the patch evolves exactly PDE::NV variables (checked by the dispatch): arrays and loops are sized for them, not for MAXV
+template <class PDE, int MODE, bool CACHE, bool FITNV = false>
 __global__ void __launch_bounds__(SLAB_NT, 2)
 fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h,
                        const long* __restrict__ slot) {
     extern __shared__ __attribute__((aligned(16))) double ring[];
     if (slot && slot[blockIdx.x] < 0) return;                      // patch not in use (workgroup-uniform)
     constexpr int NA = CACHE ? 3 : 1;
-    constexpr int NQ = CACHE ? PDE::NV : MAXV;                    // state entries kept per volume (cached variant: m == NV)
+    constexpr int NQ = (CACHE || FITNV) ? PDE::NV : MAXV;                    // state entries kept per volume (cached variant: m == NV)
     const int S = P + 2 * H;
     const int plane = S * S * V;                                  // doubles per plane
     const int aplane = S * S * NA;
-    double* auxr = ring + 3 * plane;                              // [2][S*S][NA]   (CACHE only)
+    const int slotd = slab_slot(S, V);
+    double* auxr = ring + 3 * slotd;                              // [2][S*S][NA]   (CACHE only)
     const int orow = S * V;
     double* Qp = Q + (long)blockIdx.x * S * plane;
     const int tid = threadIdx.x;
-    const int j = tid / P + H, k = tid % P + H;
-    const bool cell_ok = tid < P * P;
-    const int x = cell_ok ? j * S + k : S + 1;                     // volume index inside a plane (idle lanes: a valid one)
+    // rows of the plane at a pitch of 16 lanes (P <= 16): a 32-lane group holds two whole rows, whose volume indices are distinct
+    // mod 32 -- with V odd every per-volume LDS read of the group is conflict-free (rows packed at a pitch of P wrap around: 2 lanes
+    // of 32 collide and the instruction takes twice as long; 43 % of the LDS cycles were such conflicts)
+    const int j = (tid >> 4) + H, k = (tid & 15) + H;
+    const bool cell_ok = (tid >> 4) < P && (tid & 15) < P;
+    // volume index inside a plane; idle lanes take the first volume of their 32-lane group (same address as an active lane: a
+    // broadcast, not a bank conflict)
+    const int x = cell_ok ? j * S + k : ((((tid >> 5) << 1) < P ? ((tid >> 5) << 1) : 0) + H) * S + H;
+    const int par0 = (int)((reinterpret_cast<unsigned long long>(Qp) >> 3) & 1);
+    auto org = [&](int i) -> double* { return ring + (i % 3) * slotd + ((par0 + i * plane) & 1); };   // plane i in the ring
 
     // ---- plane i -> registers (issue) / registers -> ring slot (land)
     v2d hold[SLAB_NR];
     double hold_head = 0.0, hold_tail = 0.0;
-    auto issue = [&](int i) {
+    auto issue_to = [&](int i, v2d (&hd)[SLAB_NR], double& hh, double& ht) {
         const double* src = Qp + (long)i * plane;
-        const int head = (int)((reinterpret_cast<unsigned long long>(src) >> 3) & 1);   // first double not 16-byte aligned
+        const int head = (par0 + i * plane) & 1;                  // first double not 16-byte aligned
         const int npair = (plane - head) >> 1;
         const v2d* s2 = reinterpret_cast<const v2d*>(src + head);
         // unconditional loads at clamped (in-bounds) indices: a load under a lane condition becomes a branch with its own
@@ -420,31 +500,30 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
 #pragma unroll
         for (int r = 0; r < SLAB_NR; r++) {
             const int xx = tid + r * SLAB_NT;
-            hold[r] = s2[xx < npair ? xx : npair - 1];
+            hd[r] = s2[xx < npair ? xx : npair - 1];
         }
-        hold_head = src[0];
-        hold_tail = src[plane - 1];
+        hh = src[0];
+        ht = src[plane - 1];
     };
-    auto land = [&](int i) {
-        const double* src = Qp + (long)i * plane;
-        const int head = (int)((reinterpret_cast<unsigned long long>(src) >> 3) & 1);
+    auto land_from = [&](int i, const v2d (&hd)[SLAB_NR], double hh, double ht) {
+        const int head = (par0 + i * plane) & 1;
         const int npair = (plane - head) >> 1;
-        double* dst = ring + (i % 3) * plane;
+        double* dst = org(i);
+        v2d* d2 = reinterpret_cast<v2d*>(dst + head);             // 16-byte aligned in LDS (slot parity = HBM parity)
 #pragma unroll
         for (int r = 0; r < SLAB_NR; r++) {
             const int xx = tid + r * SLAB_NT;
-            if (xx < npair) {
-                dst[head + 2 * xx] = hold[r].x;
-                dst[head + 2 * xx + 1] = hold[r].y;
-            }
+            if (xx < npair) d2[xx] = hd[r];
         }
-        if (tid == 0 && head) dst[0] = hold_head;
-        if (tid == 1 && ((plane - head) & 1)) dst[plane - 1] = hold_tail;
+        if (tid == 0 && head) dst[0] = hh;
+        if (tid == 1 && ((plane - head) & 1)) dst[plane - 1] = ht;
     };
+    auto issue = [&](int i) { issue_to(i, hold, hold_head, hold_tail); };
+    auto land = [&](int i) { land_from(i, hold, hold_head, hold_tail); };
     // per-volume scalars of plane i (every volume of the plane, halo included: the neighbours read them)
     auto make_aux = [&](int i) {
         if constexpr (CACHE) {
-            const double* src = ring + (i % 3) * plane;
+            const double* src = org(i);
             double* dst = auxr + (i & 1) * aplane;
             for (int xx = tid; xx < S * S; xx += SLAB_NT) {
                 double q[PDE::NV], a[3];
@@ -468,52 +547,35 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
     // ---- prologue: plane H-1 -> column registers; planes H, H+1 in the ring; plane H+2 requested inside the loop.
     // The first two planes are requested together (the second through a register set that is dead afterwards).
     {
-        const double* src = Qp + (long)H * plane;
-        const int head = (int)((reinterpret_cast<unsigned long long>(src) >> 3) & 1);
-        const int npair = (plane - head) >> 1;
-        const v2d* s2 = reinterpret_cast<const v2d*>(src + head);
         v2d h2[SLAB_NR];
+        double h2_head, h2_tail;
         issue(H - 1);
-#pragma unroll
-        for (int r = 0; r < SLAB_NR; r++) {
-            const int xx = tid + r * SLAB_NT;
-            h2[r] = s2[xx < npair ? xx : npair - 1];
-        }
-        const double h2_head = src[0], h2_tail = src[plane - 1];
+        issue_to(H, h2, h2_head, h2_tail);
         land(H - 1);
-        double* dst = ring + (H % 3) * plane;
-#pragma unroll
-        for (int r = 0; r < SLAB_NR; r++) {
-            const int xx = tid + r * SLAB_NT;
-            if (xx < npair) {
-                dst[head + 2 * xx] = h2[r].x;
-                dst[head + 2 * xx + 1] = h2[r].y;
-            }
-        }
-        if (tid == 0 && head) dst[0] = h2_head;
-        if (tid == 1 && ((plane - head) & 1)) dst[plane - 1] = h2_tail;
+        land_from(H, h2, h2_head, h2_tail);
     }
     issue(H + 1);
     __syncthreads();
     make_aux(H - 1);
     make_aux(H);
     {
-        const double* r0 = ring + ((H - 1) % 3) * plane + x * V;
-        const double* r1 = ring + (H % 3) * plane + x * V;
+        const double* r0 = org(H - 1) + x * V;
+        const double* r1 = org(H) + x * V;
 #pragma unroll
-        for (int v = 0; v < NQ; v++) { qm[v] = (CACHE || v < m) ? r0[v] : 0.0; qc[v] = (CACHE || v < m) ? r1[v] : 0.0; }
+        for (int v = 0; v < NQ; v++) { qm[v] = (CACHE || FITNV || v < m) ? r0[v] : 0.0; qc[v] = (CACHE || FITNV || v < m) ? r1[v] : 0.0; }
     }
     __syncthreads();                                               // scalars visible; every lane has read plane H-1
     if constexpr (CACHE) {
 #pragma unroll
         for (int a = 0; a < 3; a++) { am[a] = auxr[((H - 1) & 1) * aplane + x * 3 + a]; ac[a] = auxr[(H & 1) * aplane + x * 3 + a]; }
-        // x-face flux between planes H-1 and H:  F* = 1/2 (f(L) + f(R)) - 1/2 s (R - L)
+        // x-face flux between planes H-1 and H, times two:  2 F* = (f(L) + f(R)) - s (R - L)   (the 1/2 goes into the final scale;
+        // explicit fma: this unit is compiled without contraction for the faithful mode's sake)
         double FL[PDE::NV], FR[PDE::NV];
         PDE::template flux_fv<0>(qm, am, FL);
         PDE::template flux_fv<0>(qc, ac, FR);
         const double sxl = fmax(PDE::template maxeig_fv<0>(qm, am), PDE::template maxeig_fv<0>(qc, ac));
 #pragma unroll
-        for (int v = 0; v < PDE::NV; v++) Fxl[v] = 0.5 * (FL[v] + FR[v]) - 0.5 * sxl * (qc[v] - qm[v]);
+        for (int v = 0; v < PDE::NV; v++) Fxl[v] = fma(-sxl, qc[v] - qm[v], FL[v] + FR[v]);
     }
     land(H + 1);                                                   // slot of plane H-2 == slot (H+1) % 3: nothing lives there yet
     __syncthreads();                                               // plane H+1 in the ring (the scalars of H-1 are in registers now)
@@ -527,10 +589,10 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
         // ---- stage 2: update volume (i, j, k) in registers
         double out[NQ];
         {
-            const double* rc = ring + (i % 3) * plane;
-            const double* rp = ring + ((i + 1) % 3) * plane;
+            const double* rc = org(i);
+            const double* rp = org(i + 1);
 #pragma unroll
-            for (int v = 0; v < NQ; v++) qp[v] = (CACHE || v < m) ? rp[x * V + v] : 0.0;
+            for (int v = 0; v < NQ; v++) qp[v] = (CACHE || FITNV || v < m) ? rp[x * V + v] : 0.0;
             if constexpr (CACHE) {
                 const double* ap = auxr + ((i + 1) & 1) * aplane;
                 const double* acp = auxr + (i & 1) * aplane;
@@ -545,7 +607,7 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
                     const double sh = fmax(PDE::template maxeig_fv<0>(qc, ac), PDE::template maxeig_fv<0>(qp, app));
 #pragma unroll
                     for (int v = 0; v < PDE::NV; v++) {
-                        const double Fh = 0.5 * (FL[v] + FR[v]) - 0.5 * sh * (qp[v] - qc[v]);
+                        const double Fh = fma(-sh, qp[v] - qc[v], FL[v] + FR[v]);
                         acc[v] = Fh - Fxl[v];
                         Fxl[v] = Fh;
                     }
@@ -567,42 +629,42 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
                         const double sf = fmax(lc, PDE::template maxeig_fv<D>(qn, an));
 #pragma unroll
                         for (int v = 0; v < PDE::NV; v++) {
-                            if (sgn) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sf * (qn[v] - qc[v]);
-                            else acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sf * (qc[v] - qn[v]);
+                            if (sgn) acc[v] += fma(-sf, qn[v] - qc[v], Fc[v] + Fn[v]);
+                            else acc[v] -= fma(-sf, qc[v] - qn[v], Fn[v] + Fc[v]);
                         }
                     }
                 });
 #pragma unroll
-                for (int v = 0; v < PDE::NV; v++) out[v] = qc[v] - dt_over_h * acc[v];
+                for (int v = 0; v < PDE::NV; v++) out[v] = fma(-0.5 * dt_over_h, acc[v], qc[v]);
 #pragma unroll
                 for (int a = 0; a < 3; a++) { am[a] = ac[a]; ac[a] = app[a]; }
             } else {
                 const double* c0 = rc + x * V;
                 const int co[3] = {i, j, k};
                 // neighbour states: axis 0 from the column registers, axes 1 and 2 from the ring
-                double qN[3][2][MAXV];
+                double qN[3][2][NQ];
 #pragma unroll
-                for (int v = 0; v < MAXV; v++) {
+                for (int v = 0; v < NQ; v++) {
                     qN[0][0][v] = qm[v];
                     qN[0][1][v] = qp[v];
-                    qN[1][0][v] = v < m ? c0[v - S * V] : 0.0;
-                    qN[1][1][v] = v < m ? c0[v + S * V] : 0.0;
-                    qN[2][0][v] = v < m ? c0[v - V] : 0.0;
-                    qN[2][1][v] = v < m ? c0[v + V] : 0.0;
+                    qN[1][0][v] = (FITNV || v < m) ? c0[v - S * V] : 0.0;
+                    qN[1][1][v] = (FITNV || v < m) ? c0[v + S * V] : 0.0;
+                    qN[2][0][v] = (FITNV || v < m) ? c0[v - V] : 0.0;
+                    qN[2][1][v] = (FITNV || v < m) ? c0[v + V] : 0.0;
                 }
                 if constexpr (MODE == 0) {
-                    double acc[MAXV];
+                    double acc[NQ];
 #pragma unroll
-                    for (int v = 0; v < MAXV; v++) acc[v] = qc[v];
+                    for (int v = 0; v < NQ; v++) acc[v] = qc[v];
 #pragma unroll
                     for (int d = 0; d < 3; d++) {
-                        double Fp[MAXV], Fm[MAXV];
+                        double Fp[NQ], Fm[NQ];
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++) { Fp[v] = 0.0; Fm[v] = 0.0; }
+                        for (int v = 0; v < NQ; v++) { Fp[v] = 0.0; Fm[v] = 0.0; }
                         if (co[d] + 1 < P + H) PDE::flux_rt(qN[d][1], d, Fp);
                         if (co[d] - 1 >= H) PDE::flux_rt(qN[d][0], d, Fm);
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++) acc[v] = acc[v] - 0.5 * Fp[v] + 0.5 * Fm[v];
+                        for (int v = 0; v < NQ; v++) acc[v] = acc[v] - 0.5 * Fp[v] + 0.5 * Fm[v];
                     }
 #pragma unroll
                     for (int d = 0; d < 3; d++) {
@@ -614,41 +676,41 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
                         acc[0] = 0.5 * dt * ((-qN[d][1][0] + qc[0]) * mp + (qN[d][0][0] - qc[0]) * mm) + acc[0];
                     }
 #pragma unroll
-                    for (int v = 0; v < MAXV; v++) out[v] = acc[v];
+                    for (int v = 0; v < NQ; v++) out[v] = acc[v];
                 } else {
-                    double acc[MAXV];
+                    double acc[NQ];
 #pragma unroll
-                    for (int v = 0; v < MAXV; v++) acc[v] = 0.0;
+                    for (int v = 0; v < NQ; v++) acc[v] = 0.0;
 #pragma unroll
                     for (int d = 0; d < 3; d++) {
-                        double Fc[MAXV], Fn[MAXV];
+                        double Fc[NQ], Fn[NQ];
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++) { Fc[v] = 0.0; Fn[v] = 0.0; }
+                        for (int v = 0; v < NQ; v++) { Fc[v] = 0.0; Fn[v] = 0.0; }
                         const double lc = PDE::maxeig(qc, d);
                         const double sp = fmax(lc, PDE::maxeig(qN[d][1], d));
                         const double sm = fmax(PDE::maxeig(qN[d][0], d), lc);
                         PDE::flux_rt(qc, d, Fc);
                         PDE::flux_rt(qN[d][1], d, Fn);
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++)
-                            if (v < m) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sp * (qN[d][1][v] - qc[v]);
+                        for (int v = 0; v < NQ; v++)
+                            if (FITNV || v < m) acc[v] += 0.5 * (Fc[v] + Fn[v]) - 0.5 * sp * (qN[d][1][v] - qc[v]);
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++) Fn[v] = 0.0;
+                        for (int v = 0; v < NQ; v++) Fn[v] = 0.0;
                         PDE::flux_rt(qN[d][0], d, Fn);
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++)
-                            if (v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qN[d][0][v]);
+                        for (int v = 0; v < NQ; v++)
+                            if (FITNV || v < m) acc[v] -= 0.5 * (Fn[v] + Fc[v]) - 0.5 * sm * (qc[v] - qN[d][0][v]);
                     }
 #pragma unroll
-                    for (int v = 0; v < MAXV; v++) out[v] = qc[v] - dt_over_h * acc[v];
+                    for (int v = 0; v < NQ; v++) out[v] = qc[v] - dt_over_h * acc[v];
                     if constexpr (pde_has_source<PDE>::value) {
-                        double Sq[MAXV];
+                        double Sq[NQ];
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++) Sq[v] = 0.0;
+                        for (int v = 0; v < NQ; v++) Sq[v] = 0.0;
                         PDE::source(qc, Sq);
 #pragma unroll
-                        for (int v = 0; v < MAXV; v++)
-                            if (v < m) out[v] += dt * Sq[v];
+                        for (int v = 0; v < NQ; v++)
+                            if (FITNV || v < m) out[v] += dt * Sq[v];
                     }
                 }
             }
@@ -664,26 +726,22 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
         if (more) land(i + 2);                                     // slot (i+2)%3 held plane i-1: its rows left LDS before (A)
         __syncthreads();                                           // (B) every stencil read of plane i is done
         if (cell_ok) {                                             // the evolved variables of (i, j, k) take their new values in place
-            double* ob = ring + (i % 3) * plane + x * V;
+            double* ob = org(i) + x * V;
 #pragma unroll
             for (int v = 0; v < NQ; v++)
-                if (CACHE || v < m) ob[v] = out[v];
+                if (CACHE || FITNV || v < m) ob[v] = out[v];
         }
         __syncthreads();                                           // (C) plane i's slot holds the new plane; plane i+2 is in the ring
         // ---- stage 3: rows j in [H, P+H) of plane i -> HBM, one contiguous block, 16-byte stores where aligned
         {
-            const double* ob = ring + (i % 3) * plane + H * orow;
+            const double* ob = org(i) + H * orow;
             double* dst = Qp + (long)i * plane + (long)H * orow;
             const int n = P * orow;
-            const int head = (int)((reinterpret_cast<unsigned long long>(dst) >> 3) & 1);
+            const int head = (par0 + i * plane + H * orow) & 1;
             const int npair = (n - head) >> 1;
             v2d* d2 = reinterpret_cast<v2d*>(dst + head);
-            for (int xx = tid; xx < npair; xx += SLAB_NT) {
-                v2d t;
-                t.x = ob[head + 2 * xx];
-                t.y = ob[head + 2 * xx + 1];
-                d2[xx] = t;
-            }
+            const v2d* o2 = reinterpret_cast<const v2d*>(ob + head);   // 16-byte aligned in LDS as in HBM
+            for (int xx = tid; xx < npair; xx += SLAB_NT) d2[xx] = o2[xx];
             if (tid == 0 && head) dst[0] = ob[0];
             if (tid == 1 && ((n - head) & 1)) dst[n - 1] = ob[n - 1];
         }
@@ -718,7 +776,7 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
         const size_t lds = (size_t)ppb * pvol * V * sizeof(double);
         // persistent form (next block requested into registers during the update of this one): Q 16-byte aligned, an even
         // number of doubles per block, a grid that fills the chip once
-        const bool persist = !cd.out && lds <= 64 * 1024 && ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (((long)ppb * pvol * V) % 2 == 0) &&
+        const bool persist = lds <= 64 * 1024 && (!cd.out || (reinterpret_cast<unsigned long long>(cd.out) & 15) == 0) && ((reinterpret_cast<unsigned long long>(Q) & 15) == 0) && (((long)ppb * pvol * V) % 2 == 0) &&
                              n_patches >= (long)ppb * 2048;
         auto persist_grid = [&](const void* kern) -> unsigned {
             int per_cu = 0, dev = 0, cus = 0;
@@ -729,6 +787,27 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
             return (unsigned)(g < nb ? g : nb);
         };
         if (DIM == 2 && P == 4 && H == 1 && m == 5 && V == 10) {    // the reference's configuration (Batched_stateless.py:9)
+#ifdef EXA_FV_REF_NT
+            {
+                constexpr int RNT = EXA_FV_REF_NT;
+                const int rppb = RNT / 16;
+                const size_t rlds = (size_t)rppb * pvol * V * sizeof(double);
+                auto kr = fv_rusanov_kernel<DIM, PDE, MODE, 1, RNT, true, FvShape<4, 1, 5, 10>, true>;
+                int per_cu = 0, dev = 0, cus = 0;
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kr), RNT, rlds);
+                hipGetDevice(&dev);
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                const long g = (long)per_cu * cus, nb = (n_patches + rppb - 1) / rppb;
+                if (persist && g > 0 && n_patches >= (long)rppb * 8192) {
+                    static bool said = false;
+                    if (!said) { fprintf(stderr, "fv ref: NT %d ppb %d per_cu %d\n", RNT, rppb, per_cu); said = true; }
+                    hipLaunchKernelGGL(kr, dim3((unsigned)(g < nb ? g : nb)), dim3(RNT), rlds, s, Q, P, H, m, V, dt, doh, n_patches, rppb, slot, cd);
+                    hipError_t e = hipGetLastError();
+                    if (e != hipSuccess) { set_error("fv_rusanov launch: %s", hipGetErrorString(e)); return -2; }
+                    return 0;
+                }
+            }
+#endif
             auto kp = fv_rusanov_kernel<DIM, PDE, MODE, 1, 256, true, FvShape<4, 1, 5, 10>, true>;
             const unsigned pg = persist ? persist_grid(reinterpret_cast<const void*>(kp)) : 0;
             if (pg > 0) hipLaunchKernelGGL(kp, dim3(pg), dim3(256), lds, s, Q, P, H, m, V, dt, doh, n_patches, ppb, slot, cd);
@@ -749,7 +828,7 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
         constexpr bool CACHE = (MODE == 1) && has_fv_cache<PDE>::value;
         if (CACHE && m != PDE::NV) { set_error("FV Rusanov: the PDE evolves %d variables, got n_real = %d", PDE::NV, m); return -1; }
         const size_t lds = slab_lds_bytes(S, V, CACHE);
-        auto kern = fv_rusanov_slab_kernel<PDE, MODE, CACHE>;
+        auto kern = CACHE ? fv_rusanov_slab_kernel<PDE, MODE, CACHE> : (m == PDE::NV ? fv_rusanov_slab_kernel<PDE, MODE, false, true> : fv_rusanov_slab_kernel<PDE, MODE, false, false>);
         if (lds > 64 * 1024) {
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (ea != hipSuccess) { set_error("hipFuncSetAttribute(fv slab, %zu B LDS): %s", lds, hipGetErrorString(ea)); return -2; }
