@@ -419,6 +419,34 @@ int exa_dg_riemann_corrector(exa_dg_plan* p, double* u_dev, const double* trace_
     return p->tab->stage_b(p->N, u_dev, trace_dev, &box, p->ncells, dt, idx, &p->ops, (hipStream_t)stream);
 }
 
+int exa_dg_has_corrector_predictor(const exa_dg_plan* p) {
+    return (p && p->tab->has_stage_ba) ? p->tab->has_stage_ba(p->N, p->n_it, p->ops.stage_a_variant) : 0;
+}
+
+int exa_dg_corrector_predictor(exa_dg_plan* p, double* u_dev, const double* trace_in_dev, double* trace_out_dev,
+                               const double* const* ghost_dev, const long* lo, const long* hi, double dt_prev, double dt,
+                               const double* dx, double* u_plain_dev, void* stream) {
+    if (!p || !u_dev || !trace_in_dev || !trace_out_dev || !dx) { set_error("exa_dg_corrector_predictor: NULL argument"); return EXA_ERR_INVALID; }
+    if (trace_in_dev == trace_out_dev) { set_error("exa_dg_corrector_predictor: the new traces need an array of their own"); return EXA_ERR_INVALID; }
+    if (!exa_dg_has_corrector_predictor(p)) {
+        set_error("exa_dg_corrector_predictor: not built for this plan (3-D, N = 6, register-resident stage A, n_picard >= 1)");
+        return EXA_ERR_INVALID;
+    }
+    for (int d = 0; d < p->dim; d++)
+        if (!(dx[d] > 0.0)) { set_error("dx[%d] must be > 0", d); return EXA_ERR_INVALID; }
+    CellBox box;
+    int rc = make_box(p, lo, hi, &box);
+    if (rc) return rc;
+    rc = use_device(p->device);
+    if (rc) return rc;
+    double idx[3];
+    inv_dx(p, dx, idx);
+    const double* gh[6];
+    for (int f = 0; f < 6; f++) gh[f] = (ghost_dev && f < 2 * p->dim) ? ghost_dev[f] : nullptr;
+    return p->tab->stage_ba(p->N, u_dev, trace_in_dev, trace_out_dev, p->ncells, &box, gh, dt_prev, dt, idx, p->n_it, &p->ops, u_plain_dev,
+                            (hipStream_t)stream);
+}
+
 int exa_dg_pack_face(exa_dg_plan* p, const double* trace_dev, int d, int side, double* buf_dev, void* stream) {
     if (!p || !trace_dev || !buf_dev || d < 0 || d >= p->dim || side < 0 || side > 1) { set_error("exa_dg_pack_face: bad argument"); return EXA_ERR_INVALID; }
     int rc = use_device(p->device);

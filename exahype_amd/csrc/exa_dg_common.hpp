@@ -80,6 +80,14 @@ template <int DIM, int N> struct Geo {
     }
 };
 
+// what the one-kernel step (exa_dg_reg.hpp, FUSE) needs of the previous step
+struct RegFuse {
+    const double* trace_in;       // traces of the previous step
+    const double* ghost[6];       // neighbour blocks' traces at the block faces (or null: periodic)
+    double dt_prev;               // the previous step's dt (its corrector)
+    double* u_plain;              // where the corrected u of the previous step goes as well, or null
+};
+
 // A box [lo, lo+nb) of cells inside the local block nc[3] (nc[2] = nb[2] = 1 in 2-D);
 // box slots are enumerated lexicographically, last axis fastest.
 struct CellBox {

@@ -46,6 +46,11 @@ struct DgLaunchTable {
     size_t (*ops_image)(int N, const DgOpsHost* h, void* dst);   // dst == nullptr: size only
     size_t (*scratch_bytes)(int N);                               // 0: the LDS kernel serves this N
     const char* (*stage_a_name)(int N, int n_it, int variant);    // the kernel stage_a launches for these settings (profiles, bench line)
+    // the step as ONE kernel: Riemann + corrector of the previous step (traces trace_in, time step dt_prev) in front of the predictor of
+    // this one (traces -> trace_out, a second array); u holds u* before and after.  u_plain: where the corrected u goes too, or null
+    int (*stage_ba)(int N, double* u, const double* trace_in, double* trace_out, long ncells, const CellBox* box, const double* const* ghost,
+                    double dt_prev, double dt, const double* idx, int n_it, const DgOpsHost* ops, double* u_plain, hipStream_t s);
+    int (*has_stage_ba)(int N, int n_it, int variant);
     // fused single-stage periodic step u_in -> u_out (2-D, n_picard = 0; exa_dg_fused.hpp), or nullptr
     int (*fused_single)(int N, const double* u_in, double* u_out, const long* nc, double dt, const double* idx,
                         const DgOpsHost* ops, hipStream_t s);

@@ -269,7 +269,7 @@ class AderDgSolver:
     STAGE_A = {"auto": 0, "lds": 1, "reg": 2}      # include/exahype_hip.h EXA_STAGE_A_*
 
     def __init__(self, dim, N, ncells, pde=PDE_EULER, n_vars=5, n_picard=-1, dx=None, device=0, part=None,
-                 backend_is_gloo=False, fused_single_stage=True, stage_a="auto", reserve_cus=None):
+                 backend_is_gloo=False, fused_single_stage=True, stage_a="auto", reserve_cus=None, one_kernel_step=False):
         torch = _torch()
         self.lib = _lib.load()
         self.dim, self.N, self.nv, self.pde = dim, N, n_vars, pde
@@ -285,10 +285,21 @@ class AderDgSolver:
         self.dx = [float(x) for x in (dx if dx is not None else [1.0 / c for c in self.nc])]
         self.nf = N ** (dim - 1)
         self.ts = 2 * n_vars * self.nf
-        self.u = torch.zeros(tuple(self.nc) + (N,) * dim + (n_vars,), dtype=torch.float64, device=self.dev)
+        self._u = torch.zeros(tuple(self.nc) + (N,) * dim + (n_vars,), dtype=torch.float64, device=self.dev)
         nc3 = self.nc + [1] * (3 - dim)
         self.trace = torch.zeros((dim, 2) + tuple(nc3) + (self.ts,), dtype=torch.float64, device=self.dev)
-        assert self.u.numel() == self.lib.exa_dg_dof_count(h) and self.trace.numel() == self.lib.exa_dg_trace_count(h)
+        assert self._u.numel() == self.lib.exa_dg_dof_count(h) and self.trace.numel() == self.lib.exa_dg_trace_count(h)
+        # The step as ONE kernel (include/exahype_hip.h exa_dg_corrector_predictor; 3-D, N = 6, register-resident stage A): step() leaves
+        # the block as (u*, traces) with the corrector PENDING, the next step's kernel applies it in front of its predictor, and reading
+        # `u` (download, max_eigenvalue, ...) applies it with the stand-alone stage B first.  Costs a second trace array.  Off by default:
+        # measured EQUAL to the two-kernel step within 1 % (22.2 against 22.1 ms per step at 64^3, profiles/r03_one_kernel_step.txt) --
+        # stage B's 2.0 ms are traded for a prologue of 0.8 ms of arithmetic + 0.9 ms of exposed trace-load latency + two barriers.
+        has = bool(self.lib.exa_dg_has_corrector_predictor(h))
+        if one_kernel_step and not has:
+            raise ValueError("one_kernel_step: not built for these settings (3-D, N = 6, stage_a 'reg', n_picard >= 1)")
+        self._one_kernel = bool(one_kernel_step)
+        self._pending_dt = None
+        self._trace2 = None
         self.part = part
         self.halo = None
         self._fused = bool(fused_single_stage) and bool(self.lib.exa_dg_has_fused_step(h))
@@ -311,9 +322,27 @@ class AderDgSolver:
             self.shell, self.interior = part.shell_and_interior(self.nc)
 
     # -- data movement ---------------------------------------------------------------------
+    @property
+    def u(self):
+        """The degrees of freedom (a pending corrector of the one-kernel step is applied first)."""
+        self.flush()
+        return self._u
+
+    @u.setter
+    def u(self, value):
+        self._pending_dt = None
+        self._u = value
+
+    def flush(self):
+        """Apply the corrector the last one-kernel step left pending (stand-alone stage B); a no-op otherwise."""
+        if self._pending_dt is not None:
+            dt, self._pending_dt = self._pending_dt, None
+            self.riemann_corrector(dt)
+
     def upload(self, u_host):
         torch = _torch()
-        self.u.copy_(torch.as_tensor(np.ascontiguousarray(u_host), dtype=torch.float64).reshape(self.u.shape))
+        self._pending_dt = None
+        self._u.copy_(torch.as_tensor(np.ascontiguousarray(u_host), dtype=torch.float64).reshape(self._u.shape))
 
     def download(self):
         return self.u.cpu().numpy()
@@ -351,9 +380,30 @@ class AderDgSolver:
             ev[1].record()
             self.stage_a_events.append(ev)
 
+    def corrector_predictor(self, dt_prev, dt, lo=None, hi=None):
+        """One-kernel step on a cell box: corrector of the previous step (its traces in self.trace, its time step dt_prev) + predictor of
+        this one; the new traces go to the second trace array (swap_traces() once every box of the step has run)."""
+        torch = _torch()
+        if self._trace2 is None:
+            self._trace2 = torch.zeros_like(self.trace)
+        ev = None
+        if self.stage_a_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        ghosts = self.halo.ghost_ptrs() if self.halo is not None else None
+        check(self.lib.exa_dg_corrector_predictor(self._plan, C.c_void_p(self._u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
+                                                  C.c_void_p(self._trace2.data_ptr()), ghosts, larr(lo) if lo is not None else None,
+                                                  larr(hi) if hi is not None else None, dt_prev, dt, darr(self.dx), None, _stream_ptr()))
+        if ev is not None:
+            ev[1].record()
+            self.stage_a_events.append(ev)
+
+    def swap_traces(self):
+        self.trace, self._trace2 = self._trace2, self.trace
+
     def riemann_corrector(self, dt, lo=None, hi=None):
         ghosts = self.halo.ghost_ptrs() if self.halo is not None else None
-        check(self.lib.exa_dg_riemann_corrector(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
+        check(self.lib.exa_dg_riemann_corrector(self._plan, C.c_void_p(self._u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
                                                 ghosts, larr(lo) if lo is not None else None,
                                                 larr(hi) if hi is not None else None, dt, darr(self.dx), _stream_ptr()))
 
@@ -387,14 +437,28 @@ class AderDgSolver:
                                                  dt, darr(self.dx), _stream_ptr()))
                 self.u, self._u2 = self._u2, self.u
                 return
+            if self._one_kernel:
+                if self._pending_dt is None:
+                    self.predictor_volume(dt)
+                else:
+                    self.corrector_predictor(self._pending_dt, dt)
+                    self.swap_traces()
+                self._pending_dt = dt
+                return
             self.predictor_volume(dt)
             self.riemann_corrector(dt)
             return
+        # (one-kernel step on a shard: the shell cells' kernel reads the ghosts the PREVIOUS step received -- complete, every step ends
+        # with the wait for its exchange -- and is done before this step's exchange overwrites them; interior cells read no ghosts)
+        fused = self._one_kernel and self._pending_dt is not None
+        stage = (lambda lo, hi: self.corrector_predictor(self._pending_dt, dt, lo, hi)) if fused else (lambda lo, hi: self.predictor_volume(dt, lo, hi))
         cur = torch.cuda.current_stream(self.dev)
         timed = self.exchange_events is not None
         mk = (lambda: torch.cuda.Event(enable_timing=True)) if timed else (lambda: None)
         for lo, hi in self.shell:                      # boundary shell first ...
-            self.predictor_volume(dt, lo, hi)
+            stage(lo, hi)
+        if fused:
+            self.trace, self._trace2 = self._trace2, self.trace      # (the pack below reads the NEW traces; the interior kernel gets them swapped back)
         ready = torch.cuda.Event(enable_timing=timed)
         ready.record(cur)
         c0, c1, i0, i1 = mk(), mk(), mk(), mk()
@@ -407,8 +471,12 @@ class AderDgSolver:
         lo, hi = self.interior                         # ... while the interior cells run stage A
         if timed:
             i0.record()
+        if fused:
+            self.trace, self._trace2 = self._trace2, self.trace
         if all(h > l for l, h in zip(lo, hi)):
-            self.predictor_volume(dt, lo, hi)
+            stage(lo, hi)
+        if fused:
+            self.swap_traces()
         if timed:
             i1.record()
         with torch.cuda.stream(self.comm_stream):
@@ -416,7 +484,10 @@ class AderDgSolver:
             if timed:
                 c1.record()
         cur.wait_stream(self.comm_stream)
-        self.riemann_corrector(dt)
+        if self._one_kernel:
+            self._pending_dt = dt
+        else:
+            self.riemann_corrector(dt)
         if timed:
             self.exchange_events.append((ready, c0, c1, i0, i1))
 

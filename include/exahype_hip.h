@@ -161,6 +161,18 @@ int exa_dg_predictor_volume_box(exa_dg_plan* plan, double* u_dev, double* trace_
 int exa_dg_riemann_corrector(exa_dg_plan* plan, double* u_dev, const double* trace_dev,
                              const double* const* ghost_dev, const long* lo, const long* hi, double dt,
                              const double* dx, void* stream);
+/* The step as ONE kernel ("fused" in the north star's sense; no counterpart in the reference): on the cell box
+ * [lo, hi) every cell first finishes the PREVIOUS step -- Rusanov flux on its faces from the traces that step left in
+ * trace_in_dev (ghost_dev as for exa_dg_riemann_corrector) and the surface corrector with dt_prev on u_dev (holding u*) --
+ * and then runs stage A with dt on the result: u_dev holds the new u* afterwards, the new traces go to trace_out_dev, a
+ * SECOND array (the neighbours still read trace_in_dev).  u_plain_dev, if not NULL, receives the corrected u of the previous
+ * step (a snapshot).  A run of n steps is  predictor_volume, (n - 1) x corrector_predictor, riemann_corrector.
+ * exa_dg_has_corrector_predictor: 1 where the plan's settings have this kernel (3-D, N = 6, register-resident stage A,
+ * n_picard >= 1), else 0 -- exa_dg_corrector_predictor then returns EXA_ERR_INVALID. */
+int exa_dg_has_corrector_predictor(const exa_dg_plan* plan);
+int exa_dg_corrector_predictor(exa_dg_plan* plan, double* u_dev, const double* trace_in_dev, double* trace_out_dev,
+                               const double* const* ghost_dev, const long* lo, const long* hi, double dt_prev, double dt,
+                               const double* dx, double* u_plain_dev, void* stream);
 /* Copy the outward traces of the block's boundary layer in direction d into a
  * contiguous buffer: side 0 -> L traces of the cells with c_d == 0 (to be sent
  * to the low neighbour, which uses it as ghost_dev[d*2+1]); side 1 -> R traces
