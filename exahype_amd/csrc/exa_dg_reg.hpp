@@ -328,9 +328,9 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         pp = side == 0 ? own : oth;
         return lt < 2 * DIM * NF && x < nb0;
     };
-    // The 20 trace values of this lane's face node.  Requested at the END of a cell, behind everything that could make the wave wait for
-    // them early (the vector memory counter runs in order, and the reload of a spilled register is such an operation), and needed by the
-    // next cell's first instructions: touch_faces() has brought their lines on chip a phase earlier, so what is exposed is a cache hit.
+    // The 20 trace values of this lane's face node: requested in the closing phases of the cell before, needed by the cell's first instructions.
+    // (The vector memory counter runs in order and the reload of a spilled register is such an operation: nothing may spill between here
+    // and there, or the wave waits for these loads at the reload.)
     [[maybe_unused]] auto fetch_faces = [&](int x, int y, int z) {
         if constexpr (FUSE) {
             const double *pm, *pp;
@@ -348,17 +348,6 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 tq[3][v] = on ? pp[(NV + v) * NF + fyl] : 0.0;
             }
         }
-    };
-    // one value per 128-byte line of the two blocks (TS doubles each): lanes fyl < ceil(TS / 16)
-    [[maybe_unused]] auto touch_faces = [&](int x, int y, int z) -> double {
-        double t = 0.0;
-        if constexpr (FUSE) {
-            const double *pm, *pp;
-            int fyl;
-            const bool on = face_blocks(x, y, z, pm, pp, fyl) && fyl * 16 < TS;
-            t = (on ? pm[fyl * 16] : 0.0) + (on ? pp[fyl * 16] : 0.0);
-        }
-        return t;
     };
     // corrector weights dt' / h_d * phi_{L,R}(xi_i) / w_i as a table in LDS behind the cells' images (read by the owners in the prologue: no
     // registers held through the Picard loop, no vector memory operation in front of the trace requests)
@@ -458,11 +447,6 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 }
             }
         }
-#ifdef EXA_FUSE_TOUCH
-        // the NEXT cell's trace lines are brought on chip a whole cell ahead (one value per 128-byte line), so that the requests in this
-        // cell's closing phases are cache hits
-        [[maybe_unused]] const double touched0 = touch_faces(cx, cy, cz);
-#endif
         double ukeep[NV];                                              // u of this cell's node (iteration starts, u*): 10 VGPRs against a global re-read in front of a fold
 #pragma unroll
         for (int v = 0; v < NV; v++) ukeep[v] = un[v];
@@ -514,9 +498,6 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 for (int v = 0; v < NV; v++) q[l][v] = 1.0;
         }
         EXA_STAMP(4);
-#ifdef EXA_FUSE_TOUCH
-        if constexpr (FUSE) asm volatile("" ::"v"(touched0));
-#endif
 
         // ---- Picard iterations 1 .. n_it - 1.  A step = [load] barrier [derive] barrier [fold]; the load of the NEXT step is issued inside the
         // fold, between its LDS loads and its arithmetic (the levels it writes are in registers since the previous iteration, and an owner
@@ -603,9 +584,6 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         }
 
         // ---- time averages (A.3): qbar | Fbar_x | Fbar_y | Fbar_z (| time-averaged source), node-major images of stride FS
-#ifdef EXA_FUSE_EARLY_FETCH
-        fetch_faces(cx, cy, cz);
-#endif
         bar();                                               // every fold has read its sums: the closing image reuses the LDS
         if (owner) {
             double wm[N];
@@ -655,11 +633,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         // the next cell's u for this lane (the registers of the iterate are free now); used by iteration 0 of the next cell
 #pragma unroll
         for (int v = 0; v < NV; v++) un[v] = (node_lane && cx < nb0) ? u_in[(cell_of(cx, cy, cz) * NN + o_n) * NV + v] : 1.0;
-#ifdef EXA_FUSE_LATE_FETCH
-        [[maybe_unused]] const double touched = touch_faces(cx, cy, cz);
-#elif !defined(EXA_FUSE_EARLY_FETCH)
-        fetch_faces(cx, cy, cz);
-#endif
+        fetch_faces(cx, cy, cz);                                        // FUSE: the next cell's traces (tried earlier / later / with a touch pass: profiles/r03_one_kernel_step.txt)
 
         // ---- volume integral (in place over Fbar_d) + face extrapolation: one round per direction (compile-time strides), tasks (v, t), t fastest
         {
@@ -721,12 +695,6 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
             for (int v2 = 0; v2 < NV; v2++) upend[v2] = us[v2];
         }
         pend_cell = active ? cell : -1;
-#ifdef EXA_FUSE_LATE_FETCH                                                  // (measured slower: 23.6 against 22.8 ms per 64^3 step)
-        if constexpr (FUSE) {
-            asm volatile("" ::"v"(touched));                             // (the touch loads have landed by now)
-            fetch_faces(cx, cy, cz);
-        }
-#endif
         bar();                                               // LDS is reused by the next cell
     }
     if (node_lane && pend_cell >= 0) {

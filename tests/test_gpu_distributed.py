@@ -59,13 +59,14 @@ G = tuple(nc[a] * part.pdims[a] for a in range(3))
 u = euler_dg_state(G + (N,) * dim, seed=42)
 dx = [1.0 / g for g in G]
 dt = 0.02 * min(dx) / (2 * N - 1)
-s = exa.AderDgSolver(dim, N, nc, dx=dx, part=part, backend_is_gloo=True)
+s = exa.AderDgSolver(dim, N, nc, dx=dx, part=part, backend_is_gloo=True, one_kernel_step=%(one)r)
 sl = tuple(slice(part.coords[a] * nc[a], (part.coords[a] + 1) * nc[a]) for a in range(3))
 s.upload(u[sl])
 ref = u.reshape(-1).copy()
-for _ in range(3):
-    s.step(dt)
-    ref = oracle.aderdg_step(ref, dt, dx, operators(N), dim, N, 5, oracle.PDE_EULER, N, G)
+for k in range(3):
+    s.step(dt * (1.0 - 0.1 * k))
+    ref = oracle.aderdg_step(ref, dt * (1.0 - 0.1 * k), dx, operators(N), dim, N, 5, oracle.PDE_EULER, N, G)
+    assert (s._pending_dt is not None) == bool(%(one)r)
 torch.cuda.synchronize()
 got = s.download()
 want = ref.reshape(u.shape)[sl]
@@ -82,7 +83,15 @@ print("rank", rank, "rel err", err)
                                          (6, (3, 2, 2), [1, 2, 2])])     # 4 ranks, the other two directions; interior box non-empty in x
 def test_sharded_step_equals_global_oracle(tmp_path, N, nc, pdims):
     world = pdims[0] * pdims[1] * pdims[2]
-    _run_ranks(tmp_path, WORKER % dict(root=ROOT, N=N, nc=nc, pdims=pdims), world)
+    _run_ranks(tmp_path, WORKER % dict(root=ROOT, N=N, nc=nc, pdims=pdims, one=False), world)
+
+
+@pytest.mark.parametrize("nc,pdims", [((2, 2, 2), [2, 1, 1]), ((3, 3, 2), [1, 2, 2])])
+def test_sharded_one_kernel_step_equals_global_oracle(tmp_path, nc, pdims):
+    """the step as one kernel on shards (exa_dg_corrector_predictor): the shell cells' kernel takes the previous step's ghosts, the new traces
+    travel while the interior cells run; 2 and 4 ranks, N = 6, a different dt every step"""
+    world = pdims[0] * pdims[1] * pdims[2]
+    _run_ranks(tmp_path, WORKER % dict(root=ROOT, N=6, nc=nc, pdims=pdims, one=True), world)
 
 
 RCCL_SELF_WORKER = r'''
