@@ -277,6 +277,8 @@ int exa_dg_plan_create(int device, int dim, int N, int n_vars, int pde, int n_pi
     p->ops.scratch = nullptr;
     p->ops.lim = nullptr;
     p->ops.stage_a_reserve = 0;
+    p->ops.origin[0] = p->ops.origin[1] = p->ops.origin[2] = 0.0;
+    p->ops.time = 0.0;
     p->ops.stage_a_variant = EXA_STAGE_A_AUTO;
     if (const char* ev = getenv("EXA_STAGE_A")) {
         if (!strcmp(ev, "lds")) p->ops.stage_a_variant = EXA_STAGE_A_LDS;
@@ -417,6 +419,13 @@ int exa_dg_riemann_corrector(exa_dg_plan* p, double* u_dev, const double* trace_
     double idx[3];
     inv_dx(p, dx, idx);
     return p->tab->stage_b(p->N, u_dev, trace_dev, &box, p->ncells, dt, idx, &p->ops, (hipStream_t)stream);
+}
+
+int exa_dg_plan_set_origin_time(exa_dg_plan* p, const double* origin, double t) {
+    if (!p) { set_error("exa_dg_plan_set_origin_time: NULL plan"); return EXA_ERR_INVALID; }
+    for (int d = 0; d < 3; d++) p->ops.origin[d] = (origin && d < p->dim) ? origin[d] : 0.0;
+    p->ops.time = t;
+    return EXA_OK;
 }
 
 int exa_dg_has_corrector_predictor(const exa_dg_plan* p) {

@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "exa_dg_common.hpp"
 #include "exa_pde.hpp"
+#include "exa_dg_plain.hpp"
 
 namespace exa {
 
@@ -1087,6 +1088,20 @@ dg_stage_a_single_kernel(const double* __restrict__ u_in, double* __restrict__ u
 // ------------------------------------------------------------------------------------------
 // Stage B
 // ------------------------------------------------------------------------------------------
+// physical coordinates of face node y of the face (d, side) of cell cc: the normal coordinate is the face's, the others the nodes'
+template <int DIM, int N> __device__ inline void face_node_coords(const PlainGeo& g, const long* cc, int d, int side, int y, double* x) {
+    int tr[2] = {0, 0};                                                // the remaining axes in ascending order, their node indices
+    if constexpr (DIM == 3) { tr[0] = y / N; tr[1] = y % N; }
+    else tr[0] = y;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (a >= DIM) x[a] = 0.0;
+        else if (a == d) x[a] = g.x0[a] + (double)(cc[a] + side) * g.h[a];
+        else { x[a] = g.x0[a] + ((double)cc[a] + g.xi[tr[k]]) * g.h[a]; k++; }
+    }
+}
+
 struct StageBArgs {
     long nc[3];            // local block
     long lo[3], nb[3];     // box origin and extent
@@ -1224,7 +1239,7 @@ dg_stage_b_kernel(double* __restrict__ u, const double* __restrict__ trace, Stag
 template <int DIM, int N, class PDE, int CPB, int NT>
 __global__ void __launch_bounds__(NT)
 dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace, StageBArgs A, long ncells, long nbox,
-                  double dt, double idx0, double idx1, double idx2, DgOps<N> ops) {
+                  double dt, double idx0, double idx1, double idx2, DgOps<N> ops, PlainGeo geo) {
     using G = Geo<DIM, N>;
     constexpr int NV = PDE::NV;
     constexpr int NN = G::NN, NF = G::NF;
@@ -1305,7 +1320,13 @@ dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace
                 Fm[k][v] = pm[(NV + v) * NF + y];
                 Fp[k][v] = pp[(NV + v) * NF + y];
             }
-            lam[task] = fmax(PDE::maxeig(qm[k], d), PDE::maxeig(qp[k], d));
+            if constexpr (pde_has_xt<PDE>::value) {
+                double xf[3];
+                face_node_coords<DIM, N>(geo, cc, d, face, y, xf);
+                lam[task] = fmax(PDE::maxeig_xt(qm[k], xf, geo.t + 0.5 * dt, d), PDE::maxeig_xt(qp[k], xf, geo.t + 0.5 * dt, d));
+            } else {
+                lam[task] = fmax(PDE::maxeig(qm[k], d), PDE::maxeig(qp[k], d));
+            }
         }
     }
     __syncthreads();
@@ -1319,6 +1340,27 @@ dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace
 #pragma unroll
             for (int v = 0; v < NV; v++)
                 fs[task * NV + v] = 0.5 * (Fm[k][v] + Fp[k][v]) - 0.5 * s * (qp[k][v] - qm[k][v]);
+            if constexpr (pde_has_ncp<PDE>::value) {
+                // path-conservative jump term D = B_d((q- + q+)/2) (q+ - q-) (straight path, midpoint), half to either side: the cell left
+                // of the face (this is its high face) takes F* + D/2, the cell right of it (its low face) F* - D/2
+                const int c = task / (NFACE * NF), r = task - c * (NFACE * NF), f = r / NF, y = r - f * NF;
+                const int d = f >> 1, face = f & 1;
+                double qa[NV], dq[NV], Dj[NV], xf[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    qa[v] = 0.5 * (qm[k][v] + qp[k][v]);
+                    dq[v] = qp[k][v] - qm[k][v];
+                    Dj[v] = 0.0;
+                }
+                if constexpr (pde_has_xt<PDE>::value) {
+                    long cc[3];
+                    cell_of(c, cc);
+                    face_node_coords<DIM, N>(geo, cc, d, face, y, xf);
+                }
+                fv_ncp<PDE>(qa, dq, xf, geo.t + 0.5 * dt, d, Dj);
+#pragma unroll
+                for (int v = 0; v < NV; v++) fs[task * NV + v] += (face == 1 ? 0.5 : -0.5) * Dj[v];
+            }
         }
     }
     __syncthreads();

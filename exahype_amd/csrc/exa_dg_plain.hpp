@@ -1,0 +1,239 @@
+// ADER-DG stage A for term sets whose terms depend on position / time (HAS_XT) or that carry a non-conservative product (HAS_NCP):
+//   q_t + div F(q, x, t) + B(q, x, t) . grad q = S(q, x, t)
+// -- the hooks the reference's harness declares for its kernel (`Unit test/correctness_test.cpp:16-41,145-155`: flux / ncp / source /
+// eigenvalue with (Q, x, h, t, dt, ...)); no ADER-DG counterpart in the reference.
+//
+// A PLAIN kernel: one workgroup per cell, two space-time images (iterate, right-hand side) and u in LDS, every thread loops over space-time
+// nodes and evaluates the flux at the N nodes of each pencil itself (N-fold redundant flux evaluations).  It serves generated term sets
+// (pde_codegen.SympyPDE) only; the built-in term sets never come here and their kernels carry none of this.  Not tuned -- correctness and
+// the same data layouts (u*, traces) as the other stage-A kernels, so that stage B and the sharded step work unchanged.
+//
+// Scheme (oracle/aderdg_numpy.py step_xt): node x = origin + (cell + xi_i) h, level time t_l = t + xi_l dt;
+//   predictor   S_l = sum_a [ D F_a(q_l, x, t_l) + B_a(q_l, x, t_l) (D q_l) ] / h_a - S(q_l, x, t_l),   q_l' <- u - dt sum_l T[l'][l] S_l
+//   averages    qbar, Fbar_a over the levels; the non-conservative term and the source enter u* point-wise:
+//               u* = u + volume(Fbar) - dt sum_l w_l sum_a B_a(q_l)(D q_l)/h_a + dt sum_l w_l S(q_l)
+//   traces      of qbar and Fbar_a as everywhere else.
+#pragma once
+#include "exa_dg_common.hpp"
+#include "exa_pde.hpp"
+
+namespace exa {
+
+struct PlainGeo {
+    double x0[3];        // physical coordinates of the block's origin
+    double h[3];         // cell size
+    double t;            // time at the start of the step
+    double xi[MAXN];     // Gauss-Legendre nodes on [0, 1]
+};
+
+template <int DIM, int N, class PDE> struct StagePlain {
+    static constexpr int NV = PDE::NV;
+    static constexpr int NN = ipow(N, DIM), NF = ipow(N, DIM - 1);
+    static constexpr int NT = 256;
+    static constexpr int IMG = N * NN * NV;                           // one space-time image
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(2 * IMG + NN * NV);
+    static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NN <= NT;
+};
+
+template <int DIM, int N, class PDE>
+__global__ void __launch_bounds__(256)
+dg_stage_a_plain_kernel(const double* u_in, double* u_out, double* __restrict__ trace, long ncells, CellBox box, double dt, double idx0,
+                        double idx1, double idx2, int n_it, DgOps<N> ops, PlainGeo geo) {
+    using SP = StagePlain<DIM, N, PDE>;
+    constexpr int NV = SP::NV, NN = SP::NN, NF = SP::NF, NT = SP::NT, IMG = SP::IMG;
+    extern __shared__ __attribute__((aligned(16))) double plain_lds[];
+    double* A = plain_lds;              // iterate      [level][node][var]
+    double* B = plain_lds + IMG;        // right-hand side, later qbar | Fbar_a  ([array][node][var])
+    double* U = plain_lds + 2 * IMG;    // u            [node][var]
+    const int tid = threadIdx.x;
+    const long cell = box.cell(blockIdx.x);
+    if (cell < 0) return;
+    long cc[3];
+    {
+        long b = blockIdx.x;
+        const long cz = b % box.nb[2];
+        b /= box.nb[2];
+        cc[0] = box.lo[0] + b / box.nb[1];
+        cc[1] = box.lo[1] + b % box.nb[1];
+        cc[2] = box.lo[2] + cz;
+    }
+    const double idx[3] = {idx0, idx1, idx2};
+    auto stride = [](int a) { return a == DIM - 1 ? 1 : (a == DIM - 2 ? N : N * N); };
+    auto digit = [&](int n, int a) { return (n / stride(a)) % N; };
+    auto coords = [&](int n, double* x) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) x[a] = a < DIM ? geo.x0[a] + ((double)cc[a] + geo.xi[digit(n, a)]) * geo.h[a] : 0.0;
+    };
+
+    for (int e = tid; e < NN * NV; e += NT) U[e] = u_in[cell * (NN * NV) + e];
+    __syncthreads();
+    for (int e = tid; e < N * NN * NV; e += NT) A[e] = U[e % (NN * NV)];
+    __syncthreads();
+
+    // right-hand side of one space-time node: flux divergence (+ B . grad q) - source; `grad` also feeds the time average of the ncp term
+    auto rhs_of = [&](int l, int n, const double* x, double tl, double* rhs, double* ncp_sum) {
+        const double* ql = A + ((long)l * NN + n) * NV;
+#pragma unroll
+        for (int v = 0; v < NV; v++) { rhs[v] = 0.0; ncp_sum[v] = 0.0; }
+        for (int a = 0; a < DIM; a++) {
+            const int ia = digit(n, a);
+            double grad[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) grad[v] = 0.0;
+            for (int j = 0; j < N; j++) {
+                const int m = n + (j - ia) * stride(a);
+                const double* qj = A + ((long)l * NN + m) * NV;
+                double xj[3] = {x[0], x[1], x[2]};
+                xj[a] = geo.x0[a] + ((double)cc[a] + geo.xi[j]) * geo.h[a];
+                double F[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) F[v] = 0.0;
+                fv_flux<PDE>(qj, xj, tl, a, F);
+                const double dij = ops.D[ia * N + j] * idx[a];
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    rhs[v] += dij * F[v];
+                    grad[v] += dij * qj[v];
+                }
+            }
+            if constexpr (pde_has_ncp<PDE>::value) {
+                double out[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) out[v] = 0.0;
+                fv_ncp<PDE>(ql, grad, x, tl, a, out);
+#pragma unroll
+                for (int v = 0; v < NV; v++) ncp_sum[v] += out[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) rhs[v] += ncp_sum[v];
+        if constexpr (pde_has_source<PDE>::value) {
+            double Sq[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) Sq[v] = 0.0;
+            fv_source<PDE>(ql, x, tl, Sq);
+#pragma unroll
+            for (int v = 0; v < NV; v++) rhs[v] -= Sq[v];
+        }
+    };
+
+    for (int it = 0; it < n_it; it++) {
+        for (int e = tid; e < N * NN; e += NT) {
+            const int l = e / NN, n = e - l * NN;
+            double x[3], rhs[NV], ncps[NV];
+            coords(n, x);
+            rhs_of(l, n, x, geo.t + geo.xi[l] * dt, rhs, ncps);
+#pragma unroll
+            for (int v = 0; v < NV; v++) B[(long)e * NV + v] = rhs[v];
+        }
+        __syncthreads();
+        for (int e = tid; e < N * NN; e += NT) {
+            const int lp = e / NN, n = e - lp * NN;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                double s = 0.0;
+                for (int l = 0; l < N; l++) s += ops.T[lp * N + l] * B[((long)l * NN + n) * NV + v];
+                A[(long)e * NV + v] = U[n * NV + v] - dt * s;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- time averages: every thread its node (NN <= NT); qbar | Fbar_a into B, the point-wise terms into `up`
+    double up[NV], qb[NV], Fb[DIM][NV];
+    const int n = tid;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        up[v] = 0.0;
+        qb[v] = 0.0;
+#pragma unroll
+        for (int a = 0; a < DIM; a++) Fb[a][v] = 0.0;
+    }
+    if (n < NN) {
+        double x[3], pw[NV];
+        coords(n, x);
+#pragma unroll
+        for (int v = 0; v < NV; v++) pw[v] = 0.0;
+        for (int l = 0; l < N; l++) {
+            const double tl = geo.t + geo.xi[l] * dt;
+            const double* ql = A + ((long)l * NN + n) * NV;
+            for (int a = 0; a < DIM; a++) {
+                double F[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) F[v] = 0.0;
+                fv_flux<PDE>(ql, x, tl, a, F);
+#pragma unroll
+                for (int v = 0; v < NV; v++) Fb[a][v] += ops.w[l] * F[v];
+            }
+#pragma unroll
+            for (int v = 0; v < NV; v++) qb[v] += ops.w[l] * ql[v];
+            if constexpr (pde_has_ncp<PDE>::value) {
+                double rhs[NV], ncps[NV];
+                rhs_of(l, n, x, tl, rhs, ncps);                          // (only its ncp part is used here)
+#pragma unroll
+                for (int v = 0; v < NV; v++) pw[v] -= ops.w[l] * ncps[v];
+            }
+            if constexpr (pde_has_source<PDE>::value) {
+                double Sq[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) Sq[v] = 0.0;
+                fv_source<PDE>(ql, x, tl, Sq);
+#pragma unroll
+                for (int v = 0; v < NV; v++) pw[v] += ops.w[l] * Sq[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) up[v] = U[n * NV + v] + dt * pw[v];
+    }
+    __syncthreads();                                                     // (B is free since the last update; nothing above writes LDS)
+    if (n < NN) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            B[((long)0 * NN + n) * NV + v] = qb[v];
+#pragma unroll
+            for (int a = 0; a < DIM; a++) B[((long)(1 + a) * NN + n) * NV + v] = Fb[a][v];
+        }
+    }
+    __syncthreads();
+
+    // ---- volume integral: u* = up + sum_a dt / h_a / w_i sum_j Kxi[i][j] Fbar_a(node with index j along a)
+    if (n < NN) {
+        for (int a = 0; a < DIM; a++) {
+            const int ia = digit(n, a);
+            const double sc = dt * idx[a] * ops.iw[ia];
+            for (int j = 0; j < N; j++) {
+                const int m = n + (j - ia) * stride(a);
+                const double k = sc * ops.Kxi[ia * N + j];
+#pragma unroll
+                for (int v = 0; v < NV; v++) up[v] += k * B[((long)(1 + a) * NN + m) * NV + v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) u_out[(cell * NN + n) * NV + v] = up[v];
+    }
+    // ---- face extrapolation: tasks (direction, face node, variable)
+    for (int e = tid; e < DIM * NF * NV; e += NT) {
+        const int a = e / (NF * NV), r = e - a * (NF * NV), v = r / NF, y = r - v * NF;
+        // first node of the pencil along a whose transverse index is y (lexicographic over the remaining axes)
+        int base;
+        if constexpr (DIM == 3) base = a == 0 ? y : (a == 1 ? (y / N) * N * N + y % N : y * N);
+        else base = a == 0 ? y : y * N;
+        double qL = 0.0, qR = 0.0, FL = 0.0, FR = 0.0;
+        for (int j = 0; j < N; j++) {
+            const int m = base + j * stride(a);
+            const double q = B[((long)0 * NN + m) * NV + v], F = B[((long)(1 + a) * NN + m) * NV + v];
+            qL += ops.phiL[j] * q;
+            qR += ops.phiR[j] * q;
+            FL += ops.phiL[j] * F;
+            FR += ops.phiR[j] * F;
+        }
+        double* tl = trace + (((long)a * 2 + 0) * ncells + cell) * (2 * NV * NF);
+        double* tr = trace + (((long)a * 2 + 1) * ncells + cell) * (2 * NV * NF);
+        tl[(0 * NV + v) * NF + y] = qL;
+        tl[(1 * NV + v) * NF + y] = FL;
+        tr[(0 * NV + v) * NF + y] = qR;
+        tr[(1 * NV + v) * NF + y] = FR;
+    }
+}
+
+}  // namespace exa

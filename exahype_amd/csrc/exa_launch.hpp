@@ -16,6 +16,8 @@ struct DgOpsHost {
     void* scratch; // per-workgroup slabs of the level-streamed stage A (N whose cell image exceeds LDS), else null
     int stage_a_reserve;   // workgroups the persistent stage-A grids stay below the resident count (CUs left to the exchange's kernels)
     int stage_a_variant;   // 0: the build's default; 1: LDS-resident space-time image; 2: register-resident iterate (where built: 3-D, N = 6)
+    double origin[3];      // physical coordinates of the block's origin and the time at the start of the step: what term sets with
+    double time;           // position- / time-dependent terms (HAS_XT) are evaluated at (exa_dg_plan_set_origin_time; default 0)
 };
 // dg_operators_host.cpp: Gauss-Legendre nodes by Newton, barycentric derivative
 // matrix, K1 inverse by Gauss-Jordan, all in long double.

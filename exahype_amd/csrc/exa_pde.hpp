@@ -34,6 +34,35 @@ constexpr double GAMMA = 1.4;
 template <class P, class = void> struct pde_has_source : std::false_type {};
 template <class P> struct pde_has_source<P, std::void_t<decltype(P::HAS_SOURCE)>> : std::bool_constant<P::HAS_SOURCE> {};
 
+// Optional members of a PDE struct: `static constexpr bool HAS_XT = true` with flux_xt(q, x, t, d, F), maxeig_xt(q, x, t, d) and (with
+// HAS_SOURCE) source_xt(q, x, t, S) -- the terms may depend on the position x[3] (FV: the volume centre; ADER-DG: the node) and the time t, as the hooks of the reference's
+// harness are declared (`Unit test/correctness_test.cpp:16-41`: flux / maxEigenvalue / sourceTerm(Q, x, h, t, dt, ...)).  The built-in
+// term sets have none, and for them the coordinates below are dead code: their kernels are unchanged.
+template <class P, class = void> struct pde_has_xt : std::false_type {};
+template <class P> struct pde_has_xt<P, std::void_t<decltype(P::HAS_XT)>> : std::bool_constant<P::HAS_XT> {};
+template <class PDE> __device__ inline void fv_flux(const double* q, const double* x, double t, int d, double* F) {
+    if constexpr (pde_has_xt<PDE>::value) PDE::flux_xt(q, x, t, d, F);
+    else PDE::flux_rt(q, d, F);
+}
+template <class PDE> __device__ inline double fv_eig(const double* q, const double* x, double t, int d) {
+    if constexpr (pde_has_xt<PDE>::value) return PDE::maxeig_xt(q, x, t, d);
+    else return PDE::maxeig(q, d);
+}
+template <class PDE> __device__ inline void fv_source(const double* q, const double* x, double t, double* S) {
+    if constexpr (pde_has_xt<PDE>::value) PDE::source_xt(q, x, t, S);
+    else PDE::source(q, S);
+}
+// Optional: `static constexpr bool HAS_NCP = true` with ncp(q, dq, d, out) (HAS_XT: ncp_xt(q, dq, x, t, d, out)) = B_d(q) dq, the
+// non-conservative product of q_t + div F(q) + B(q) . grad q = S(q) -- the `ncp` slot of the kernel the reference's harness targets
+// (`Unit test/correctness_test.cpp:145-155`: <Flux, ncp, Source, Eigen>).  Corrected Rusanov mode only: across a face the jump term
+// D = B_d((q_L + q_R) / 2) (q_R - q_L) (straight path, midpoint) goes half to either side, as ExaHyPE 2's FV Rusanov solver does.
+template <class P, class = void> struct pde_has_ncp : std::false_type {};
+template <class P> struct pde_has_ncp<P, std::void_t<decltype(P::HAS_NCP)>> : std::bool_constant<P::HAS_NCP> {};
+template <class PDE> __device__ inline void fv_ncp(const double* q, const double* dq, const double* x, double t, int d, double* out) {
+    if constexpr (pde_has_xt<PDE>::value) PDE::ncp_xt(q, dq, x, t, d, out);
+    else PDE::ncp(q, dq, d, out);
+}
+
 // 1/x from v_rcp_f64 + EXA_RCP_NR Newton steps.  Measured on MI355X against the IEEE quotient
 // (scripts/rcp_accuracy.hip, 4M values): bare v_rcp_f64 2.6e8 ulp, one step <= 11 ulp (2.5e-15 relative), two
 // steps exact.  One step is the default: used by the ADER-DG kernels only (tolerance 1e-10; 2 % of stage A);

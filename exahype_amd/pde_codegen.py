@@ -56,13 +56,15 @@ class SympyPDE:
         ncp(q, dq, d) (or ncp(q, dq, x, t, d)) -> n_vars expressions (optional): the non-conservative product B_d(q) dq of
         q_t + div F(q) + B(q) . grad q = S(q), dq = the jump (or gradient) of q along direction d -- the `ncp` slot of the kernel the
         harness targets (`Unit test/correctness_test.cpp:145-155`).  Built into the corrected FV Rusanov update (path-conservative jump
-        term, half to either side of a face); the ADER-DG kernels have no such term yet, so a term set with an ncp builds the FV unit only.
+        term, half to either side of a face) and into ADER-DG (exa_dg_plain.hpp: B . grad q point-wise in the predictor and in the
+        time-averaged update, the same jump term in the Riemann solve).
 
         Position and time: the harness declares the terms as flux / maxEigenvalue / sourceTerm(Q, x, h, t, dt, ...)
         (`Unit test/correctness_test.cpp:16-41`).  Callables that take them -- flux(q, x, t, d), max_eigenvalue(q, x, t, d),
-        source(q, x, t), x = (x0, x1, x2) the volume centre -- generate a term set with HAS_XT; the FV patch kernels hand it the
-        coordinates (`exa_fv_time_step_device_oop`: cell centres and t; the in-place call: patches centred at the origin, t = 0).  The
-        ADER-DG kernels do not carry node coordinates yet: such a term set builds the FV unit only and an ADER-DG plan for it is refused."""
+        source(q, x, t), x = (x0, x1, x2) -- generate a term set with HAS_XT; the FV patch kernels hand it the volume centres
+        (`exa_fv_time_step_device_oop`: cell centres and t; the in-place call: patches centred at the origin, t = 0), ADER-DG the node
+        coordinates and level times (`exa_dg_plan_set_origin_time`).  Term sets with HAS_XT or an ncp run ADER-DG through a plain,
+        untuned stage-A kernel (2-D N <= 8, 3-D N <= 6); the tuned kernels serve the others."""
         if not 1 <= n_vars <= 8:
             raise ValueError("n_vars must be 1..8")
         self.n_vars, self.max_dim, self.name = n_vars, max_dim, name
@@ -204,6 +206,12 @@ struct UserPDE {
         return 0.0;
     }
     __device__ static inline void flux_rt(const double* q, int d, double* F) { const double x0[3] = {0.0, 0.0, 0.0}; flux_xt(q, x0, 0.0, d, F); }
+    template <int D> __device__ static inline void flux(const double* q, const double*, double* F) { flux_rt(q, D, F); }
+    template <int D> __device__ static inline void flux_scaled(const double* q, const double*, double sc, double* F) {
+        flux_rt(q, D, F);
+#pragma unroll
+        for (int v = 0; v < NV; v++) F[v] *= sc;
+    }
     __device__ static inline double maxeig(const double* q, int d) { const double x0[3] = {0.0, 0.0, 0.0}; return maxeig_xt(q, x0, 0.0, d); }
     __device__ static inline double maxeig_fast(const double* q, int d) { return maxeig(q, d); }
 %s};
@@ -213,7 +221,7 @@ struct UserPDE {
     def key(self):
         h = hashlib.sha256(self.source().encode())
         for f in ("dg_inst.hip", "fv_rusanov.hip", "exa_dg_kernels.hpp", "exa_dg_stream.hpp", "exa_dg_reg.hpp", "exa_dg_fused.hpp",
-                  "exa_dg_common.hpp", "exa_launch.hpp", "exa_pde.hpp"):
+                  "exa_dg_common.hpp", "exa_launch.hpp", "exa_pde.hpp", "exa_dg_plain.hpp", "exa_dg_m8.hpp"):
             h.update(open(os.path.join(CSRC, f), "rb").read())
         return h.hexdigest()[:16]
 
@@ -238,11 +246,9 @@ struct UserPDE {
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         common = [hipcc, "-O3", "-fPIC", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-Wno-unused-function",
                   "-Wno-pass-failed", "-I", CSRC, "-DEXA_PDE_ID=100", '-DEXA_USER_PDE_HEADER="%s"' % hdr]
-        units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"])]
-        if not self.uses_xt and self.ncp_exprs is None:         # (the ADER-DG kernels carry no node coordinates and no ncp term yet)
-            units.append(("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2"]))
-            if self.max_dim >= 3:
-                units.append(("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3"]))
+        units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"]), ("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2"])]
+        if self.max_dim >= 3:
+            units.append(("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3"]))
         procs = [(o, subprocess.Popen(common + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(d, o)],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for src, o, extra in units]
         for o, p in procs:

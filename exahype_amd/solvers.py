@@ -269,7 +269,7 @@ class AderDgSolver:
     STAGE_A = {"auto": 0, "lds": 1, "reg": 2}      # include/exahype_hip.h EXA_STAGE_A_*
 
     def __init__(self, dim, N, ncells, pde=PDE_EULER, n_vars=5, n_picard=-1, dx=None, device=0, part=None,
-                 backend_is_gloo=False, fused_single_stage=True, stage_a="auto", reserve_cus=None, one_kernel_step=False):
+                 backend_is_gloo=False, fused_single_stage=True, stage_a="auto", reserve_cus=None, one_kernel_step=False, origin=None, time=0.0):
         torch = _torch()
         self.lib = _lib.load()
         self.dim, self.N, self.nv, self.pde = dim, N, n_vars, pde
@@ -283,6 +283,11 @@ class AderDgSolver:
         if stage_a != "auto":
             check(self.lib.exa_dg_plan_set_stage_a(h, self.STAGE_A[stage_a]))
         self.dx = [float(x) for x in (dx if dx is not None else [1.0 / c for c in self.nc])]
+        # where and when (term sets with position- / time-dependent terms only: include/exahype_hip.h exa_dg_plan_set_origin_time): physical
+        # coordinates of the GLOBAL grid's origin -- a shard adds its offset -- and the time, which step() advances
+        go = [float(x) for x in (origin if origin is not None else [0.0] * dim)]
+        self.origin = [go[a] + (part.coords[a] * self.nc[a] * self.dx[a] if part is not None else 0.0) for a in range(dim)]
+        self.time = float(time)
         self.nf = N ** (dim - 1)
         self.ts = 2 * n_vars * self.nf
         self._u = torch.zeros(tuple(self.nc) + (N,) * dim + (n_vars,), dtype=torch.float64, device=self.dev)
@@ -367,7 +372,11 @@ class AderDgSolver:
         return dict(flop_a=v[0].value, flop_b=v[1].value, bytes_a=v[2].value, bytes_b=v[3].value)
 
     # -- kernels -------------------------------------------------------------------------------
+    def _where_and_when(self):
+        check(self.lib.exa_dg_plan_set_origin_time(self._plan, darr(self.origin), self.time))
+
     def predictor_volume(self, dt, lo=None, hi=None):
+        self._where_and_when()
         ev = None
         if self.stage_a_events is not None:
             torch = _torch()
@@ -403,6 +412,7 @@ class AderDgSolver:
 
     def riemann_corrector(self, dt, lo=None, hi=None):
         ghosts = self.halo.ghost_ptrs() if self.halo is not None else None
+        self._where_and_when()
         check(self.lib.exa_dg_riemann_corrector(self._plan, C.c_void_p(self._u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
                                                 ghosts, larr(lo) if lo is not None else None,
                                                 larr(hi) if hi is not None else None, dt, darr(self.dx), _stream_ptr()))
@@ -424,7 +434,11 @@ class AderDgSolver:
                                                 C.c_void_p(self.halo.send[d * 2 + side].data_ptr()), _stream_ptr()))
 
     def step(self, dt):
-        """One ADER-DG time step of the block (periodic, or one shard of a periodic grid)."""
+        """One ADER-DG time step of the block (periodic, or one shard of a periodic grid); advances `time`."""
+        self._step(dt)
+        self.time += dt
+
+    def _step(self, dt):
         torch = _torch()
         if self.halo is None:
             if self._fused:

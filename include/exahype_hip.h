@@ -161,6 +161,11 @@ int exa_dg_predictor_volume_box(exa_dg_plan* plan, double* u_dev, double* trace_
 int exa_dg_riemann_corrector(exa_dg_plan* plan, double* u_dev, const double* trace_dev,
                              const double* const* ghost_dev, const long* lo, const long* hi, double dt,
                              const double* dx, void* stream);
+/* Where and when: physical coordinates of the local block's origin (dim entries, NULL = 0) and the time at the start of the next
+ * step.  Only term sets whose terms depend on position / time see them (pde_codegen.SympyPDE with flux(q, x, t, d) ...: the hooks
+ * `Unit test/correctness_test.cpp:16-41` declares with (Q, x, h, t, dt)): stage A evaluates them at the nodes x = origin + (cell + xi_i) dx
+ * and the level times t + xi_l dt, stage B at the face nodes and t + dt / 2.  Call it before every step of such a term set. */
+int exa_dg_plan_set_origin_time(exa_dg_plan* plan, const double* origin, double t);
 /* The step as ONE kernel ("fused" in the north star's sense; no counterpart in the reference): on the cell box
  * [lo, hi) every cell first finishes the PREVIOUS step -- Rusanov flux on its faces from the traces that step left in
  * trace_in_dev (ghost_dev as for exa_dg_riemann_corrector) and the surface corrector with dt_prev on u_dev (holding u*) --

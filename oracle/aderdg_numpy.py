@@ -202,3 +202,109 @@ def node_coords(grid, N, ops):
         sh[d + a] = N
         xs.append(x.reshape(sh))
     return xs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Terms that depend on position / time, non-conservative product:  q_t + div F(q, x, t) + B(q, x, t) . grad q = S(q, x, t)
+# (the hooks `Unit test/correctness_test.cpp:16-41,145-155` declares; no ADER-DG in the reference: parity unpinned).
+# pde: flux(q, x, t, a), maxeig(q, x, t, a), optional source(q, x, t), ncp(q, dq, x, t, a); x = list of d arrays broadcastable
+# to q[..., 0].  Restated by exahype_amd/csrc/exa_dg_plain.hpp (stage A) and dg_stage_b_dense_kernel (stage B).
+# ---------------------------------------------------------------------------------------------------------------------
+def _coords(grid, N, ops, dx, origin, lead=0):
+    """node coordinates: list over axes of arrays shaped [grid..., (lead singleton axes), nodes...] with 1 where they do not vary"""
+    d = len(grid)
+    xs = []
+    for a in range(d):
+        x = origin[a] + (np.arange(grid[a])[:, None] + ops['xi'][None, :]) * dx[a]      # [cells, N]
+        sh = [1] * (2 * d + lead)
+        sh[a] = grid[a]
+        sh[d + lead + a] = N
+        xs.append(x.reshape(sh))
+    while len(xs) < 3:
+        xs.append(np.zeros([1] * (2 * d + lead)))
+    return xs
+
+
+def step_xt(u, dt, dx, ops, pde, t=0.0, origin=None, n_it=None, stages=False):
+    d = _dim(u)
+    N = ops['N']
+    grid = u.shape[:d]
+    origin = [0.0] * d if origin is None else origin
+    if n_it is None:
+        n_it = N
+    D, iK1, F0, w, xi = ops['D'], ops['iK1'], ops['F0'], ops['w'], ops['xi']
+    has_src, has_ncp = hasattr(pde, "source"), hasattr(pde, "ncp")
+    x4 = _coords(grid, N, ops, dx, origin, lead=1)                  # with a time axis at position d
+    tshape = [1] * (2 * d + 1)
+    tshape[d] = N
+    tl = (t + xi * dt).reshape(tshape)
+    ue = np.expand_dims(u, d)
+    q = np.repeat(ue, N, axis=d)
+    tsv = tshape + [1]
+
+    def ncp_sum(qq):
+        out = np.zeros_like(qq)
+        for a in range(d):
+            out += pde.ncp(qq, _apply(D, qq, d + 1 + a) / dx[a], x4, tl, a)
+        return out
+
+    for _ in range(n_it):
+        S = np.zeros_like(q)
+        for a in range(d):
+            S += _apply(D, pde.flux(q, x4, tl, a), d + 1 + a) / dx[a]
+        if has_ncp:
+            S += ncp_sum(q)
+        if has_src:
+            S -= pde.source(q, x4, tl)
+        R = F0.reshape(tsv) * ue - dt * w.reshape(tsv) * S
+        q = _apply(iK1, R, d)
+    qbar = np.tensordot(w, q, axes=([0], [d]))
+    Fbar = [np.tensordot(w, pde.flux(q, x4, tl, a), axes=([0], [d])) for a in range(d)]
+    us = volume(u, Fbar, dt, dx, ops)
+    if has_ncp:
+        us = us - dt * np.tensordot(w, ncp_sum(q), axes=([0], [d]))
+    if has_src:
+        us = us + dt * np.tensordot(w, pde.source(q, x4, tl), axes=([0], [d]))
+    tr = traces(qbar, Fbar, ops)
+    # Riemann solve at the RIGHT face of every cell, at the face nodes and t + dt / 2; with an ncp the jump term D goes half to either side
+    x3 = _coords(grid, N, ops, dx, origin)
+    tf = t + 0.5 * dt
+    un = us.copy()
+    for a in range(d):
+        qL, qR, FL, FR = tr[a]
+        xf = []
+        for b in range(3):
+            if b >= d:
+                xf.append(np.zeros([1] * (2 * d - 1)))
+            elif b == a:
+                sh = [1] * (2 * d - 1)
+                sh[a] = grid[a]
+                xf.append((origin[a] + (np.arange(grid[a]) + 1.0) * dx[a]).reshape(sh))
+            else:
+                xf.append(np.squeeze(x3[b], axis=d + a))               # node axis a removed
+        qm, Fm = qR, FR
+        qp, Fp = np.roll(qL, -1, axis=a), np.roll(FL, -1, axis=a)
+        lam = np.maximum(pde.maxeig(qm, xf, tf, a) * np.ones(qm.shape[:-1]), pde.maxeig(qp, xf, tf, a) * np.ones(qm.shape[:-1]))
+        s = lam.max(axis=tuple(range(d, d + d - 1)), keepdims=True) if d > 1 else lam
+        Fs = 0.5 * (Fm + Fp) - 0.5 * s[..., None] * (qp - qm)
+        Dj = pde.ncp(0.5 * (qm + qp), qp - qm, xf, tf, a) if has_ncp else np.zeros_like(Fs)
+        # the cell left of the face (its high face) takes F* + D/2, the cell right of it (its low face) F* - D/2.  The right cell evaluates
+        # the face at ITS low-face coordinates: the same point, except across the periodic wrap
+        xlo = list(xf)
+        sh = [1] * (2 * d - 1)
+        sh[a] = grid[a]
+        xlo[a] = (origin[a] + np.arange(grid[a]) * dx[a]).reshape(sh)
+        qm_l, qp_l = np.roll(qR, 1, axis=a), qL                       # low face of every cell: minus = left neighbour's R, plus = own L
+        lam_l = np.maximum(pde.maxeig(qm_l, xlo, tf, a) * np.ones(qL.shape[:-1]), pde.maxeig(qp_l, xlo, tf, a) * np.ones(qL.shape[:-1]))
+        s_l = lam_l.max(axis=tuple(range(d, d + d - 1)), keepdims=True) if d > 1 else lam_l
+        Flo = 0.5 * (np.roll(FR, 1, axis=a) + FL) - 0.5 * s_l[..., None] * (qp_l - qm_l)
+        if has_ncp:
+            Flo = Flo - 0.5 * pde.ncp(0.5 * (qm_l + qp_l), qp_l - qm_l, xlo, tf, a)
+        Fhi = Fs + 0.5 * Dj
+        sh = [1] * us.ndim
+        sh[d + a] = N
+        un -= dt / dx[a] * (ops['phiR'].reshape(sh) * np.expand_dims(Fhi, d + a) - ops['phiL'].reshape(sh) * np.expand_dims(Flo, d + a)) / w.reshape(sh)
+    if stages:
+        return dict(q=q, qbar=qbar, Fbar=Fbar, ustar=us, traces=tr, unew=un)
+    return un
+

@@ -94,6 +94,46 @@ def test_sharded_one_kernel_step_equals_global_oracle(tmp_path, nc, pdims):
     _run_ranks(tmp_path, WORKER % dict(root=ROOT, N=6, nc=nc, pdims=pdims, one=True), world)
 
 
+XT_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from exahype_amd import solvers as exa
+from oracle import aderdg_numpy as A
+from oracle.dg_operators import operators
+from tests.test_user_pde import coupled_xt_ncp_system, OracleXtPDE
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dim, N, nc, pdims = 2, 3, (2, 3), [2, 1]
+part = exa.CartesianPartition(world, rank, dim, pdims)
+G = tuple(nc[a] * part.pdims[a] for a in range(dim))
+p = coupled_xt_ncp_system(max_dim=2)
+u = 1.0 + 0.3 * np.random.default_rng(5).random(G + (N,) * dim + (3,))
+dx = [0.9 / G[0], 1.1 / G[1]]
+origin = [0.25, -0.5]
+dt = 0.03 * min(dx) / (2 * N - 1)
+s = exa.AderDgSolver(dim, N, nc, pde=p.register(), n_vars=3, dx=dx, part=part, backend_is_gloo=True, origin=origin, time=0.4)
+sl = tuple(slice(part.coords[a] * nc[a], (part.coords[a] + 1) * nc[a]) for a in range(dim))
+s.upload(u[sl])
+ref, t = u.copy(), 0.4
+for _ in range(3):
+    s.step(dt)
+    ref = A.step_xt(ref, dt, dx, operators(N), OracleXtPDE(p), t=t, origin=origin)
+    t += dt
+torch.cuda.synchronize()
+err = np.max(np.abs(s.download() - ref[sl])) / np.max(np.abs(ref))
+assert err < 1e-10, err
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "rel err", err)
+'''
+
+
+def test_sharded_step_with_position_dependent_terms_and_ncp(tmp_path):
+    """two shards of a 2-D grid, term set with node coordinates, level times and a non-conservative product: every shard evaluates the terms at
+    ITS coordinates (origin + shard offset), the ncp jump term crosses the shard boundary through the ghost traces"""
+    _run_ranks(tmp_path, XT_WORKER % dict(root=ROOT), 2)
+
+
 RCCL_SELF_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)

@@ -433,7 +433,7 @@ def _volume_centres(centres, P, H, h, dim):
     return x
 
 
-def test_position_and_time_dependent_terms_generate_an_fv_only_term_set():
+def test_position_and_time_dependent_terms_generate_an_xt_term_set():
     p = variable_coefficient_system()
     assert p.uses_xt and "HAS_XT = true" in p.source() and "flux_xt(const double* q, const double* x, double t" in p.source()
     assert not reaction_advection().uses_xt and "HAS_XT" not in reaction_advection().source()
@@ -540,9 +540,6 @@ def test_cell_data_flavour_through_the_printer():
     out = hp.run_cell_data(np.ascontiguousarray(Q), 1e-3, t=0.3, cell_centre=centres, cell_size=0.5)
     kern = exa.FVRusanovKernel(2, 5, 1, 2, 0, 3, pde=p.register(), mode=exa.FV_RUSANOV)
     assert np.array_equal(out, kern.time_step_oop(np.ascontiguousarray(Q), 1e-3, 0.1, t=0.3, centres=centres))
-    from exahype_amd._lib import ExaHypeHipError
-    with pytest.raises(ExaHypeHipError):                         # ADER-DG kernels carry no node coordinates yet: refused, not ignored
-        exa.AderDgSolver(2, 3, (2, 2), pde=p.register(), n_vars=2)
 
 
 # ---- non-conservative product ------------------------------------------------------------------------------------------------------------
@@ -604,3 +601,149 @@ def test_ncp_fv_rusanov_vs_numpy(dim, P):
         kk.time_step(o, dt, h)
         outs.append(o)
     assert np.max(np.abs(outs[0] - outs[1])) < 1e-14
+
+
+# ---- ADER-DG with node coordinates, level times and a non-conservative product (exa_dg_plain.hpp, dg_stage_b_dense_kernel) ----------------
+class OracleXtPDE:
+    """A SympyPDE lambdified for oracle/aderdg_numpy.py step_xt: flux(q, x, t, a), maxeig, source, ncp with x a list of three arrays."""
+
+    def __init__(self, spde):
+        self.m = spde.n_vars
+        xt = list(spde.x) + [spde.t]
+        self._f = [sympy.lambdify(list(spde.q) + xt, spde.flux_exprs[d], "numpy") for d in range(spde.max_dim)]
+        self._e = [sympy.lambdify(list(spde.q) + xt, spde.eig_exprs[d], "numpy") for d in range(spde.max_dim)]
+        if spde.source_exprs is not None:
+            s_ = sympy.lambdify(list(spde.q) + xt, spde.source_exprs, "numpy")
+            self.source = lambda q, x, t: self._stack(s_(*self._qs(q), *x, t), q)
+        if spde.ncp_exprs is not None:
+            n_ = [sympy.lambdify(list(spde.q) + list(spde.dq) + xt, spde.ncp_exprs[d], "numpy") for d in range(spde.max_dim)]
+            self.ncp = lambda q, dq, x, t, a: self._stack(n_[a](*self._qs(q), *self._qs(dq), *x, t), q)
+
+    def _qs(self, q):
+        return [q[..., v] for v in range(self.m)]
+
+    @staticmethod
+    def _stack(outs, q):
+        return np.stack([np.broadcast_to(o, q.shape[:-1]) for o in outs], axis=-1)
+
+    def flux(self, q, x, t, a):
+        return self._stack(self._f[a](*self._qs(q), *x, t), q)
+
+    def maxeig(self, q, x, t, a):
+        return np.broadcast_to(self._e[a](*self._qs(q), *x, t), q.shape[:-1])
+
+
+def coupled_xt_ncp_system(max_dim=3, with_ncp=True, with_xt=True):
+    """Three coupled fields: advection with a velocity that depends on position and time, a non-conservative coupling B(q) grad q, a source that
+    depends on both -- every slot of the harness's kernel (`Unit test/correctness_test.cpp:145-155`: Flux, ncp, Source, Eigen) at once."""
+    from exahype_amd.pde_codegen import SympyPDE
+    R = sympy.Rational
+    if with_xt:
+        vel = lambda x, t, d: (1, R(-1, 2), R(3, 4))[d] + R(3, 10) * sympy.sin(2 * x[(d + 1) % max_dim] + t)
+        flux = lambda q, x, t, d: [vel(x, t, d) * q[0], R(3, 4) * vel(x, t, d) * q[1] + R(1, 5) * q[0] * q[2], R(1, 2) * vel(x, t, d) * q[2]]
+        eig = lambda q, x, t, d: sympy.Abs(vel(x, t, d)) + R(1, 5) * sympy.Abs(q[0])
+        source = lambda q, x, t: [x[0] * sympy.cos(t) - q[0] * x[1], q[0] - 2 * q[1] + t, R(1, 2) * q[1] * x[0]]
+        ncp = (lambda q, dq, x, t, d: [R(3, 10) * q[1] * dq[0], (R(1, 5) + R(1, 10) * x[d]) * q[0] * dq[2], R(1, 4) * dq[1] * (1 + t)]) if with_ncp else None
+    else:
+        a = (1.0, -0.5, 0.75)
+        flux = lambda q, d: [a[d] * q[0], 0.75 * a[d] * q[1] + 0.2 * q[0] * q[2], 0.5 * a[d] * q[2]]
+        eig = lambda q, d: sympy.Float(abs(a[d])) + 0.2 * sympy.Abs(q[0])
+        source = None
+        ncp = lambda q, dq, d: [0.3 * q[1] * dq[0], 0.2 * q[0] * dq[2], 0.25 * dq[1]]
+    return SympyPDE(3, flux=flux, max_eigenvalue=eig, source=source, ncp=ncp, max_dim=max_dim,
+                    name="coupled_%s%s" % ("xt" if with_xt else "", "_ncp" if ncp is not None else ""))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,N,nc,with_ncp,with_xt", [(2, 3, (3, 2), False, True), (2, 4, (2, 3), True, True), (3, 3, (2, 2, 2), True, True),
+                                                         (3, 6, (2, 1, 2), True, True), (3, 4, (1, 2, 2), True, False), (2, 8, (2, 2), True, True)])
+def test_aderdg_position_time_and_ncp_vs_numpy_oracle(dim, N, nc, with_ncp, with_xt):
+    """ADER-DG for q_t + div F(q, x, t) + B(q, x, t) . grad q = S(q, x, t): node coordinates and level times reach the terms, the ncp enters the
+    predictor, the time-averaged update and the Riemann solve.  Against oracle/aderdg_numpy.py step_xt with the SAME lambdified expressions
+    (parity unpinned against the reference, which holds no ADER-DG); three steps with a non-zero origin and start time, full predictor and
+    single-stage scheme."""
+    from exahype_amd import solvers as exa
+    from oracle import aderdg_numpy as A
+    from oracle.dg_operators import operators
+    p = coupled_xt_ncp_system(max_dim=dim, with_ncp=with_ncp, with_xt=with_xt)
+    assert p.uses_xt == with_xt
+    o = OracleXtPDE(p)
+    rng = np.random.default_rng(100 * dim + N)
+    u = 1.0 + 0.3 * rng.random(tuple(nc) + (N,) * dim + (3,))
+    dx = [(0.9, 1.1, 0.7)[a] / nc[a] for a in range(dim)]
+    origin = [0.25, -0.5, 1.0][:dim]
+    dt = 0.03 * min(dx) / (2 * N - 1)
+    for n_picard in (-1, 0, 2):
+        s = exa.AderDgSolver(dim, N, nc, pde=p.register(), n_vars=3, dx=dx, n_picard=n_picard, origin=origin, time=0.4)
+        assert "plain" in s.stage_a_kernel_name()
+        s.upload(u)
+        ref, t = u.copy(), 0.4
+        for k in range(3):
+            s.step(dt * (1 + 0.1 * k))
+            ref = A.step_xt(ref, dt * (1 + 0.1 * k), dx, operators(N), o, t=t, origin=origin, n_it=N if n_picard < 0 else n_picard)
+            t += dt * (1 + 0.1 * k)
+        assert abs(s.time - t) < 1e-15
+        assert np.max(np.abs(s.download() - ref)) / np.max(np.abs(ref)) < 1e-10, n_picard
+    # every slot is really in the kernels: the oracle without it is far from what they produced
+    for slot in (["ncp"] if with_ncp else []) + (["source"] if with_xt else []):
+        o2 = OracleXtPDE(p)
+        delattr(o2, slot)
+        ref0, t = u.copy(), 0.4
+        for k in range(3):
+            ref0 = A.step_xt(ref0, dt * (1 + 0.1 * k), dx, operators(N), o2, t=t, origin=origin, n_it=2)
+            t += dt * (1 + 0.1 * k)
+        assert np.max(np.abs(s.download() - ref0)) > 1e-7, slot
+
+
+@pytest.mark.gpu
+def test_aderdg_constant_coefficient_advection_as_flux_or_as_ncp():
+    """a . grad q written as div(a q) or as the non-conservative product B = a: for a constant a and Rusanov's flux the two ADER-DG schemes
+    coincide (the jump term of the path-conservative form is a (q+ - q-), the flux form's central part the same)."""
+    from exahype_amd import solvers as exa
+    from exahype_amd.pde_codegen import SympyPDE
+    a = (1.0, 0.5, -0.25)
+    as_flux = SympyPDE(2, flux=lambda q, d: [a[d] * q[0], a[d] * q[1]], max_eigenvalue=lambda q, d: sympy.Float(1.0), max_dim=3, name="dg_adv_flux")
+    as_ncp = SympyPDE(2, flux=lambda q, d: [0 * q[0], 0 * q[1]], max_eigenvalue=lambda q, d: sympy.Float(1.0),
+                      ncp=lambda q, dq, d: [a[d] * dq[0], a[d] * dq[1]], max_dim=3, name="dg_adv_ncp")
+    N, nc = 4, (2, 2, 2)
+    u = 1.0 + 0.3 * np.random.default_rng(8).random(nc + (N,) * 3 + (2,))
+    outs = []
+    for p in (as_flux, as_ncp):
+        s = exa.AderDgSolver(3, N, nc, pde=p.register(), n_vars=2)
+        s.upload(u)
+        for _ in range(3):
+            s.step(2e-3)
+        outs.append(s.download())
+    assert np.max(np.abs(outs[0] - outs[1])) < 1e-12
+    assert np.max(np.abs(outs[0] - u)) > 1e-3
+
+
+@pytest.mark.gpu
+def test_aderdg_manufactured_solution_with_position_and_time():
+    """q(x, t) = 2 + sin(2 pi (x0 - t)) cos(2 pi x1) solves q_t + div(a q) = S(x, t) with a = (1, 1/2) and the source read off the exact solution;
+    the DG solution converges to it at the scheme's order when coordinates and time reach the source (p = 3: error ratio ~16 per halving)."""
+    from exahype_amd import solvers as exa
+    from exahype_amd.pde_codegen import SympyPDE
+    from oracle.dg_operators import operators
+    pi = sympy.pi
+    exact = lambda x, t: 2 + sympy.sin(2 * pi * (x[0] - t)) * sympy.cos(2 * pi * x[1])
+    def src(q, x, t):
+        e = exact(x, t)
+        return [sympy.diff(e, t) + sympy.diff(e, x[0]) + sympy.Rational(1, 2) * sympy.diff(e, x[1])]
+    p = SympyPDE(1, flux=lambda q, x, t, d: [(1, sympy.Rational(1, 2))[d] * q[0]], max_eigenvalue=lambda q, x, t, d: sympy.Float(1.0),
+                 source=src, max_dim=2, name="manufactured_dg")
+    N, errs = 4, []
+    xi = operators(N)["xi"]
+    f = sympy.lambdify(list(p.x[:2]) + [p.t], exact(p.x, p.t), "numpy")
+    for n in (4, 8):
+        X = (np.arange(n)[:, None] + xi[None, :]) / n
+        x0, x1 = X[:, None, :, None], X[None, :, None, :]
+        s = exa.AderDgSolver(2, N, (n, n), pde=p.register(), n_vars=1)
+        s.upload(np.broadcast_to(f(x0, x1, 0.0), (n, n, N, N))[..., None].copy())
+        steps = 8 * n // 4
+        dt = 0.1 / steps
+        for _ in range(steps):
+            s.step(dt)
+        errs.append(np.max(np.abs(s.download()[..., 0] - f(x0, x1, 0.1))))
+    assert errs[1] < errs[0] / 8 and errs[1] < 2e-4, errs
+
