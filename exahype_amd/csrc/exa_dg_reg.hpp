@@ -147,7 +147,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
 #ifndef EXA_REG_FULL_BARRIER
 #define EXA_REG_FULL_BARRIER 0
 #endif
-        if constexpr (!EXA_REG_FULL_BARRIER) {
+        if constexpr (FUSE && !EXA_REG_FULL_BARRIER) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -367,8 +367,11 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     }
 #endif
 
-    double upend[NV];                                                  // u* of the cell just finished, stored during the next cell (see there)
-    long pend_cell = -1;
+    // FUSE: u* of the cell just finished is stored during the next cell (see there); the plain predictor stores it at once and keeps
+    // __syncthreads() (measured: deferring it there costs 1 %, 158.4 against 156.9 ms per 128^3 launch)
+    constexpr bool DEFER = FUSE;
+    [[maybe_unused]] double upend[NV];
+    [[maybe_unused]] long pend_cell = -1;
 #pragma unroll
     for (int v = 0; v < NV; v++) upend[v] = 0.0;
     for (long trip = 0; trip < trips; trip++) {
@@ -452,10 +455,12 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         for (int v = 0; v < NV; v++) ukeep[v] = un[v];
         // u* of the PREVIOUS cell goes out here, behind the first use of what was requested for this cell: the vector memory counter runs
         // in order, so stores issued between those requests and their first use would have to be acknowledged first
-        if (node_lane && pend_cell >= 0) {
-            double* uo = u_out + (pend_cell * NN + o_n) * NV;
+        if constexpr (DEFER) {
+            if (node_lane && pend_cell >= 0) {
+                double* uo = u_out + (pend_cell * NN + o_n) * NV;
 #pragma unroll
-            for (int v = 0; v < NV; v++) uo[v] = upend[v];
+                for (int v = 0; v < NV; v++) uo[v] = upend[v];
+            }
         }
         if (owner) put_level(0, un);
         EXA_STAMP(0);
@@ -691,16 +696,24 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
 #pragma unroll
                 for (int d = 0; d < DIM; d++) us[v2] += EXA_LD(((1 + d) * NV + v2) * FS + o_n);
             }
+            if constexpr (DEFER) {
 #pragma unroll
-            for (int v2 = 0; v2 < NV; v2++) upend[v2] = us[v2];
+                for (int v2 = 0; v2 < NV; v2++) upend[v2] = us[v2];
+            } else {
+                double* uo = u_out + (cell * NN + o_n) * NV;
+#pragma unroll
+                for (int v2 = 0; v2 < NV; v2++) uo[v2] = us[v2];
+            }
         }
-        pend_cell = active ? cell : -1;
+        if constexpr (DEFER) pend_cell = active ? cell : -1;
         bar();                                               // LDS is reused by the next cell
     }
-    if (node_lane && pend_cell >= 0) {
-        double* uo = u_out + (pend_cell * NN + o_n) * NV;
+    if constexpr (DEFER) {
+        if (node_lane && pend_cell >= 0) {
+            double* uo = u_out + (pend_cell * NN + o_n) * NV;
 #pragma unroll
-        for (int v = 0; v < NV; v++) uo[v] = upend[v];
+            for (int v = 0; v < NV; v++) uo[v] = upend[v];
+        }
     }
 #ifndef EXA_REG_LOCKSTEP
     if constexpr (CPW == 2) {

@@ -45,7 +45,7 @@ for cfg in cfg1 cfg4 fv-ref; do
   head -5 $OUT/kernel_stats_$cfg.csv
 done
 echo "== traffic"
-traffic cfg2 dg_stage_a_reg_kernel '{"kernel": "dg_stage_a_reg_kernel<6, exa::Euler, 2>", "cells": 128, "order": 5, "algorithmic_bytes_per_launch": 72477573120.0}' -- --steps 2 --warmup 1 --no-other-configs
+traffic cfg2 dg_stage_a_reg_kernel '{"kernel": "dg_stage_a_reg_kernel<6, exa::Euler, 2, false>", "cells": 128, "order": 5, "algorithmic_bytes_per_launch": 72477573120.0}' -- --steps 2 --warmup 1 --no-other-configs
 traffic cfg1 dg_fused_single_kernel '{"algorithmic_bytes_per_launch": 1006632960.0}' -- --config cfg1 --steps 5 --warmup 2
 traffic cfg4 dg_stage_a_m8_kernel '{"kernel": "dg_stage_a_m8_kernel<exa::Euler>", "cells": 64}' -- --config cfg4 --steps 2 --warmup 1
 traffic fv_ref fv_rusanov_kernel '{"algorithmic_bytes_per_launch": 3690987520.0}' -- --config fv-ref --steps 5 --warmup 2
