@@ -26,10 +26,22 @@ template <int N> struct FusedTile { static constexpr int T = N <= 4 ? 4 : (N <= 
 template <int N, class PDE, int TX, int TY> struct FusedSingle {
     static constexpr int NV = PDE::NV, NN = N * N;
     static constexpr int LX = TX + 2, LY = TY + 2, LC = LX * LY;
-    static constexpr int CS = NV * NN;                          // doubles per cell
+    static constexpr int CS = NV * NN;                          // doubles per cell in HBM
+    // LDS image of a cell (r3): the HBM order [node][var] at a cell stride CSP = 4 mod 8, the four unused corner cells of the ring left out
+    // (slot()).  The first layout ([var][node], cell stride NV N^2 = 80 = 16 mod 32) was transposed on the way in and out (5-way conflicted
+    // stores at a 16-double stride) and its pencil reads were 4-way conflicted: 72 % of the LDS cycles were bank conflicts.  Now the load
+    // and the store are plain copies, and a 32-lane group of x-pencil tasks -- N pencils x 32 / N cells -- reads distinct banks: the lanes
+    // of a cell are NV apart, cells whose slots differ mod 8 sit on the 8 multiples of 4; the lane order pairs the tile's cell rows (0, 2)
+    // and (1, 3) for that.  (The y pencils of a cell are N NV = 20 apart, multiples of 4 like the cells: still 4-way.  A row pitch of N + 1
+    // nodes makes them conflict-free too, but the image then no longer leaves room for three workgroups per CU: 0.243 against 0.204 ms.)
+    static constexpr int RS = N * NV;                           // row stride
+    static constexpr int CSP = N * RS + ((4 - (N * RS) % 8) + 8) % 8;
+    static constexpr int LCS = LX * LY - 4;                     // cell slots
+    __host__ __device__ static constexpr int slot(int lc) { return lc - (lc < LY - 1 ? 1 : (lc < LX * LY - LY ? 2 : 3)); }
     static constexpr int NFX = (TX + 1) * TY, NFY = TX * (TY + 1), NFACE = NFX + NFY;
-    static constexpr int FS = 2 * 2 * NV * N;                   // per face: [side][field q|F][var][node]
-    static constexpr int LAMO = LC * CS + NFACE * FS;           // offset of the eigenvalue table [face][side][node]
+    static constexpr int FS0 = 2 * 2 * NV * N;                  // per face: [side][field q|F][var][node]
+    static constexpr int FS = FS0 + ((4 - FS0 % 8) + 8) % 8;    // (stride = 4 mod 8, as the cells)
+    static constexpr int LAMO = LCS * CSP + NFACE * FS;         // offset of the eigenvalue table [face][side][node]
     static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(LAMO + NFACE * 2 * N);
     static constexpr int T_INT = TX * TY * 2 * N, T_HX = 2 * TY * N, T_HY = 2 * TX * N;
     static constexpr int NT = 256;
@@ -42,16 +54,18 @@ __global__ void __launch_bounds__(256)
 dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, long ncx, long ncy, long tiles_y, double dt,
                        double idx0, double idx1, const void* __restrict__ ops_raw) {
     using FU = FusedSingle<N, PDE, TX, TY>;
-    constexpr int NV = PDE::NV, NN = N * N, LY = FU::LY, LC = FU::LC, CS = FU::CS;
+    constexpr int NV = PDE::NV, LY = FU::LY, LC = FU::LC, CS = FU::CS, CSP = FU::CSP, RS = FU::RS;
     constexpr int NFX = FU::NFX, NFACE = FU::NFACE, FS = FU::FS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* U = lds;
-    double* FT = lds + LC * CS;
+    double* FT = lds + FU::LCS * CSP;
+
     double* LAM = lds + FU::LAMO;
     const int tid = threadIdx.x;
     const long lb = xcd_contiguous(blockIdx.x, gridDim.x);      // neighbouring tiles (shared rings) on the same XCD's L2
     const long tx0 = (lb / tiles_y) * TX, ty0 = (lb % tiles_y) * TY;
     const double idx[2] = {idx0, idx1};
+    const bool wide = CS % 2 == 0 && CSP % 2 == 0 && ((reinterpret_cast<unsigned long long>(u_in) | reinterpret_cast<unsigned long long>(u_out)) & 15) == 0;
 
     // ---- A: load the tile and its ring (corners are never used); global cell of every local cell first (one lane
     //      each: the periodic wrap costs 64-bit remainders, far too slow to repeat per element)
@@ -60,29 +74,43 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
         const int lx = tid / LY - 1, ly = tid % LY - 1;
         long g = -1;
         if (!((lx < 0 || lx >= TX) && (ly < 0 || ly >= TY))) {
-            const long gx = ((tx0 + lx) % ncx + ncx) % ncx, gy = ((ty0 + ly) % ncy + ncy) % ncy;
+            long gx = tx0 + lx, gy = ty0 + ly;                   // periodic wrap by comparison (a 64-bit remainder is ~100 instructions);
+            gx = gx < 0 ? gx + ncx : gx;                         // a ring cell of a partial tile at the end of the block may lie a period further
+            gy = gy < 0 ? gy + ncy : gy;
+            while (gx >= ncx) gx -= ncx;
+            while (gy >= ncy) gy -= ncy;
             g = gx * ncy + gy;
         }
         gcell[tid] = g;
     }
     __syncthreads();
     {
-        constexpr int PER = (LC * CS + FU::NT - 1) / FU::NT;     // all loads of a lane in flight before the first use
-        double tmp[PER];
+        // 16-byte copies where the cell size is even and the arrays are 16-byte aligned, 8-byte copies otherwise
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        if (wide) {
+            constexpr int CP = CS / 2;
+            constexpr int PER = (LC * CP + FU::NT - 1) / FU::NT; // all loads of a lane in flight before the first use
+            v2d_t tmp[PER];
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int e = tid + k * FU::NT;
-            const int lc = e < LC * CS ? e / CS : 0;
-            const long g = gcell[lc];
-            tmp[k] = (e < LC * CS && g >= 0) ? u_in[g * CS + (e - lc * CS)] : 0.0;
-        }
+            for (int k = 0; k < PER; k++) {
+                const int e = tid + k * FU::NT;
+                const int lc = e < LC * CP ? e / CP : 0;
+                const long g = gcell[lc];
+                tmp[k] = (e < LC * CP && g >= 0) ? reinterpret_cast<const v2d_t*>(u_in + g * CS)[e - lc * CP] : v2d_t{0.0, 0.0};
+            }
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int e = tid + k * FU::NT;
-            if (e < LC * CS) {
-                const int lc = e / CS, r = e - lc * CS;
-                const int n = r / NV, v = r - n * NV;
-                U[lc * CS + v * NN + n] = tmp[k];
+            for (int k = 0; k < PER; k++) {
+                const int e = tid + k * FU::NT;
+                if (e < LC * CP) {
+                    const int lc = e / CP;
+                    if (gcell[lc] >= 0) reinterpret_cast<v2d_t*>(U + FU::slot(lc) * CSP)[e - lc * CP] = tmp[k];
+                }
+            }
+        } else {
+            for (int e = tid; e < LC * CS; e += FU::NT) {
+                const int lc = e / CS;
+                const long g = gcell[lc];
+                if (g >= 0) U[FU::slot(lc) * CSP + (e - lc * CS)] = u_in[g * CS + (e - lc * CS)];
             }
         }
     }
@@ -98,6 +126,7 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
             p_t = k % N; k /= N;
             p_ly = k % TY; k /= TY;
             p_lx = k % TX; p_d = k / TX;
+            if constexpr (TX == 4) p_lx = ((p_lx & 1) << 1) | (p_lx >> 1);      // rows in the order 0, 2, 1, 3 (see FusedSingle)
         } else if ((k -= FU::T_INT) < FU::T_HX) {
             p_d = 0;
             p_t = k % N; k /= N;
@@ -110,9 +139,9 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
             p_task = false;
         }
     }
-    const int p_lc = (p_lx + 1) * LY + p_ly + 1;
-    const int p_n0 = p_d == 0 ? p_t : p_t * N;                    // first node of the pencil, stride p_ns
-    const int p_ns = p_d == 0 ? N : 1;
+    const int p_lc = FU::slot((p_lx + 1) * LY + p_ly + 1);
+    const int p_n0 = p_d == 0 ? p_t * NV : p_t * RS;              // first node of the pencil (offset in the cell's image), stride p_ns
+    const int p_ns = p_d == 0 ? RS : NV;
     // faces of the pencil's cell along p_d: index or -1 (outside the tile's face table)
     int fL = -1, fR = -1;
     if (p_task) {
@@ -134,7 +163,7 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
         for (int j = 0; j < N; j++) {
             double a[PDE::NAUX];
 #pragma unroll
-            for (int v = 0; v < NV; v++) q[j][v] = EXA_FLD(&U[p_lc * CS + v * NN + p_n0 + j * p_ns]);
+            for (int v = 0; v < NV; v++) q[j][v] = EXA_FLD(&U[p_lc * CSP + p_n0 + j * p_ns + v]);
             PDE::aux_fast(q[j], a);
 #pragma unroll
             for (int v = 0; v < NV; v++) F[j][v] = 0.0;
@@ -206,20 +235,31 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
                 const double FsL = EXA_FLD(&FT[fL * FS + v * N + p_t]), FsR = EXA_FLD(&FT[fR * FS + v * N + p_t]);
 #pragma unroll
                 for (int i = 0; i < N; i++)
-                    U[p_lc * CS + v * NN + p_n0 + i * p_ns] = EXA_FLD(&U[p_lc * CS + v * NN + p_n0 + i * p_ns]) + vol[i][v] - sc * o->iw[i] * (o->phiR[i] * FsR - o->phiL[i] * FsL);
+                    U[p_lc * CSP + p_n0 + i * p_ns + v] = EXA_FLD(&U[p_lc * CSP + p_n0 + i * p_ns + v]) + vol[i][v] - sc * o->iw[i] * (o->phiR[i] * FsR - o->phiL[i] * FsL);
             }
         }
         __syncthreads();
     }
 
     // ---- D: store the tile
-    for (int e = tid; e < TX * TY * CS; e += FU::NT) {
-        const int c = e / CS, r = e - c * CS;
-        const int lx = c / TY, ly = c - lx * TY;
-        const long gx = tx0 + lx, gy = ty0 + ly;
-        if (gx >= ncx || gy >= ncy) continue;                    // partial tile at the end of the block
-        const int n = r / NV, v = r - n * NV;
-        u_out[(gx * ncy + gy) * CS + r] = U[((lx + 1) * LY + ly + 1) * CS + v * NN + n];
+    if (wide) {
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        constexpr int CP = CS / 2;
+        for (int e = tid; e < TX * TY * CP; e += FU::NT) {
+            const int c = e / CP, r = e - c * CP;
+            const int lx = c / TY, ly = c - lx * TY;
+            const long gx = tx0 + lx, gy = ty0 + ly;
+            if (gx >= ncx || gy >= ncy) continue;                // partial tile at the end of the block
+            reinterpret_cast<v2d_t*>(u_out + (gx * ncy + gy) * CS)[r] = reinterpret_cast<const v2d_t*>(U + FU::slot((lx + 1) * LY + ly + 1) * CSP)[r];
+        }
+    } else {
+        for (int e = tid; e < TX * TY * CS; e += FU::NT) {
+            const int c = e / CS, r = e - c * CS;
+            const int lx = c / TY, ly = c - lx * TY;
+            const long gx = tx0 + lx, gy = ty0 + ly;
+            if (gx >= ncx || gy >= ncy) continue;
+            u_out[(gx * ncy + gy) * CS + r] = U[FU::slot((lx + 1) * LY + ly + 1) * CSP + r];
+        }
     }
 }
 
