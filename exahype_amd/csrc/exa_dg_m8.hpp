@@ -21,6 +21,9 @@
 //   fold    owners: acc[l'] += -dt T[l'][l] (S_x + S_y + S_z)_l, started from u: after the last step acc is the new iterate
 // LDS image and strides as exa_dg_stream.hpp (StreamGeo<8>: row stride 9, plane stride 72; Q | A | B | flux scalars).
 #pragma once
+#ifndef EXA_M8_SCHED
+#define EXA_M8_SCHED 0
+#endif
 #include "exa_dg_stream.hpp"
 
 namespace exa {
@@ -51,7 +54,10 @@ template <class PDE> struct StageAM8 {
     static constexpr int AXO = 3 * QSZ;                               // flux scalars
     static constexpr int PIC_D = 3 * QSZ + NA * VS;
     static constexpr int FIN_D = (pde_has_source<PDE>::value ? 5 : 4) * NV * G::SL;
-    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(PIC_D > FIN_D ? PIC_D : FIN_D);
+    static constexpr int IMG_D = PIC_D > FIN_D ? PIC_D : FIN_D;
+    // behind the cell's image: the lane tables as 16-bit offsets [table][direction][lane] (0xffff = no pencil) -- read in front of every
+    // round instead of being held in (and spilled from) registers through the Picard loop
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)IMG_D + sizeof(unsigned short) * 2 * 3 * NT;
     static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && G::NN == NT;
     // lane tables behind the operator image: [levels in the step: 2, 1][direction][lane] -> level slot * SL + first node of the lane's pencil, -1 idle
     static constexpr int TAB_INTS = 2 * 3 * NT;
@@ -89,20 +95,24 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
     // derive role: node pair j = lane >> 4 of the pencil the lane tables give this lane (one per direction; the 16 pencils of a wave
     // have bank residues that keep the pairs k, k + 1 of a 32-lane group apart)
     const int d_j = lane >> 4;
-    int d_off2[3];
+    unsigned short* ltab = reinterpret_cast<unsigned short*>(lds + SA::IMG_D);
 #pragma unroll
-    for (int d = 0; d < 3; d++) d_off2[d] = tab[d * NT + tid];
+    for (int k = 0; k < 6; k++) ltab[k * NT + tid] = (unsigned short)tab[k * NT + tid];      // (-1 -> 0xffff)
+    __syncthreads();
     // A operands of this lane: Ee[k][i], Eo[k][i] with i = lane & 3, k = lane >> 4 (DgOps::DEO packing: [j][i] even part, [j][H + i] odd part)
     const double aEe = static_cast<const DgOps<N>*>(ops_raw)->DEO[d_j * N + (lane & 3)];
     const double aEo = static_cast<const DgOps<N>*>(ops_raw)->DEO[d_j * N + H + (lane & 3)];
 
     // one round: direction D, results to A (D = 1), B (D = 2) or into hx (D = 0)
-    auto round = [&](auto dc, const int (&offs)[3], double (&hx)[2][NV]) {
+    auto round = [&](auto dc, int tb, double (&hx)[2][NV]) {
         constexpr int D = decltype(dc)::value;
-        if (offs[D] >= 0) {                                           // (wave-uniform: a wave has 16 pencils or none)
+        const int off = ltab[(tb * 3 + D) * NT + opaque_v(tid)];
+        if (off != 0xffff) {                                          // (wave-uniform: a wave has 16 pencils or none)
             constexpr int ps = G::pstride(D);
-            const int off = opaque_v(offs[D]);
-            const int na = off + d_j * ps, nb = off + (N - 1 - d_j) * ps;
+            // (lane constants behind opaque copies: hoisted out of the cell loop their products with the strides live through the Picard
+            // iterations and spill -- 96 B of scratch, reloaded in front of every round)
+            const int dj = opaque_v(d_j);
+            const int na = off + dj * ps, nb = off + (N - 1 - dj) * ps;
             double qa[NV], qb[NV], aa[NA], ab[NA], Fa[NV], Fb[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
@@ -132,19 +142,26 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             }
         }
     };
-    auto derive = [&](const int (&offs)[3]) {
+    auto derive = [&](int tb) {                                       // tb: 0 = steps of two levels, 1 = iteration 0 (one level)
         double hx[2][NV];
-        round(std::integral_constant<int, 1>{}, offs, hx);
-        round(std::integral_constant<int, 2>{}, offs, hx);
-        round(std::integral_constant<int, 0>{}, offs, hx);           // x last: its sums wait in registers for the barrier
+        round(std::integral_constant<int, 1>{}, tb, hx);
+#if EXA_M8_SCHED >= 2
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        round(std::integral_constant<int, 2>{}, tb, hx);
+#if EXA_M8_SCHED >= 2
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        round(std::integral_constant<int, 0>{}, tb, hx);             // x last: its sums wait in registers for the barrier
         __syncthreads();                                              // every read of Q is done; S_y (A), S_z (B) are complete
-        if (offs[0] >= 0) {                                           // Q := S_x
+        const int off = ltab[(tb * 3 + 0) * NT + opaque_v(tid)];
+        if (off != 0xffff) {                                          // Q := S_x
             constexpr int ps = G::pstride(0);
-            const int off = opaque_v(offs[0]);
+            const int dj = opaque_v(d_j);
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                lds[off + d_j * ps + v * VS] = hx[0][v];
-                lds[off + (N - 1 - d_j) * ps + v * VS] = hx[1][v];
+                lds[off + dj * ps + v * VS] = hx[0][v];
+                lds[off + (N - 1 - dj) * ps + v * VS] = hx[1][v];
             }
         }
         __syncthreads();
@@ -171,10 +188,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         __syncthreads();
         EXA_STAMP(1);
         {
-            int d_off1[3];                                            // iteration 0 has its own table (one level: four waves per round)
-#pragma unroll
-            for (int d = 0; d < 3; d++) d_off1[d] = tab[(3 + d) * NT + tid];
-            derive(d_off1);
+            derive(1);                                               // iteration 0 has its own table (one level: four waves per round)
         }
         EXA_STAMP(2);
         {
@@ -216,17 +230,32 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 constexpr int st = decltype(sc_)::value;
                 constexpr int l0 = 2 * st;
                 EXA_STAMP(4);
+#if EXA_M8_SCHED >= 1
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 __syncthreads();
+#if EXA_M8_SCHED >= 1
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 EXA_STAMP(5);
-                derive(d_off2);
-                EXA_STAMP(6);
-                double Tm[2 * N];                                      // -dt T[l'][l0 + ls], l' fastest
-                sload<2 * N>(step_here<N>(step_raw)->TdtT + l0 * N, Tm);
+#ifdef EXA_M8_EARLY_U
                 [[maybe_unused]] double uu[NV];
                 if constexpr (st == 0) {
 #pragma unroll
                     for (int v = 0; v < NV; v++) uu[v] = up[v];
                 }
+#endif
+                derive(0);
+                EXA_STAMP(6);
+                double Tm[2 * N];                                      // -dt T[l'][l0 + ls], l' fastest
+                sload<2 * N>(step_here<N>(step_raw)->TdtT + l0 * N, Tm);
+#ifndef EXA_M8_EARLY_U
+                [[maybe_unused]] double uu[NV];
+                if constexpr (st == 0) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++) uu[v] = up[v];
+                }
+#endif
                 double Sx[2][NV];                                      // (summed as they arrive: 160 VGPRs of iterate + accumulators leave no room for 30 loads in flight)
 #pragma unroll
                 for (int ls = 0; ls < 2; ls++)
