@@ -21,9 +21,6 @@
 //   fold    owners: acc[l'] += -dt T[l'][l] (S_x + S_y + S_z)_l, started from u: after the last step acc is the new iterate
 // LDS image and strides as exa_dg_stream.hpp (StreamGeo<8>: row stride 9, plane stride 72; Q | A | B | flux scalars).
 #pragma once
-#ifndef EXA_M8_SCHED
-#define EXA_M8_SCHED 0
-#endif
 #include "exa_dg_stream.hpp"
 
 namespace exa {
@@ -142,17 +139,86 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             }
         }
     };
+#ifndef EXA_M8_PIPE          // (measured SLOWER: 117.3 against 98.2 ms per 64^3 launch -- the 28 VGPRs of the next round's operands do not exist: 204 B of scratch)
+#define EXA_M8_PIPE 0
+#endif
     auto derive = [&](int tb) {                                       // tb: 0 = steps of two levels, 1 = iteration 0 (one level)
         double hx[2][NV];
+#if EXA_M8_PIPE
+        // software-pipelined over the three rounds: the LDS loads of the next round are issued in front of the matrix instructions and the
+        // stores of the current one (they read Q and the scalars, which no round writes), so their latency and the store queue overlap
+        const int t_ = opaque_v(tid), dj = opaque_v(d_j);
+        struct Ops { double qa[NV], qb[NV], aa[NA], ab[NA]; };
+        auto offs = [&](auto dc, int& na, int& nb) -> bool {
+            constexpr int D = decltype(dc)::value;
+            const int off = ltab[(tb * 3 + D) * NT + t_];
+            const bool have = off != 0xffff;                          // (wave-uniform: a wave has 16 pencils or none)
+            const int o2 = have ? off : 0;
+            na = o2 + dj * G::pstride(D);
+            nb = o2 + (N - 1 - dj) * G::pstride(D);
+            return have;
+        };
+        auto load = [&](int na, int nb, Ops& r) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                r.qa[v] = EXA_SLD(na + v * VS);
+                r.qb[v] = EXA_SLD(nb + v * VS);
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                r.aa[k] = EXA_SLD(AXO + na + k * VS);
+                r.ab[k] = EXA_SLD(AXO + nb + k * VS);
+            }
+        };
+        auto evenodd = [&](auto dc, const Ops& r, double (&e)[NV], double (&o)[NV]) {
+            constexpr int D = decltype(dc)::value;
+            double Fa[NV], Fb[NV];
+            const double sc = D == 0 ? idx0 : (D == 1 ? idx1 : idx2);
+            PDE::template flux_scaled<D>(r.qa, r.aa, sc, Fa);
+            PDE::template flux_scaled<D>(r.qb, r.ab, sc, Fb);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                e[v] = Fa[v] + Fb[v];
+                o[v] = Fa[v] - Fb[v];
+            }
+        };
+        auto matrix = [&](auto dc, bool have, int na, int nb, const double (&e)[NV], const double (&o)[NV]) {
+            constexpr int D = decltype(dc)::value;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                const double Pv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, e[v], 0.0, 0, 0, 0);
+                const double Mv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, o[v], 0.0, 0, 0, 0);
+                if constexpr (D == 0) {
+                    hx[0][v] = Mv + Pv;
+                    hx[1][v] = Mv - Pv;
+                } else if (have) {
+                    lds[D * QSZ + na + v * VS] = Mv + Pv;
+                    lds[D * QSZ + nb + v * VS] = Mv - Pv;
+                }
+            }
+        };
+        using D0 = std::integral_constant<int, 0>;
+        using D1 = std::integral_constant<int, 1>;
+        using D2 = std::integral_constant<int, 2>;
+        int na1, nb1, na2, nb2, na0, nb0;
+        const bool h1 = offs(D1{}, na1, nb1), h2 = offs(D2{}, na2, nb2), h0 = offs(D0{}, na0, nb0);
+        (void)h0;
+        Ops r;
+        double e[NV], o[NV];
+        load(na1, nb1, r);
+        evenodd(D1{}, r, e, o);
+        load(na2, nb2, r);                                            // (round z's operands: in flight under round y's matrix instructions and stores)
+        matrix(D1{}, h1, na1, nb1, e, o);
+        evenodd(D2{}, r, e, o);
+        load(na0, nb0, r);
+        matrix(D2{}, h2, na2, nb2, e, o);
+        evenodd(D0{}, r, e, o);
+        matrix(D0{}, true, 0, 0, e, o);                               // x last: its sums wait in registers for the barrier
+#else
         round(std::integral_constant<int, 1>{}, tb, hx);
-#if EXA_M8_SCHED >= 2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         round(std::integral_constant<int, 2>{}, tb, hx);
-#if EXA_M8_SCHED >= 2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         round(std::integral_constant<int, 0>{}, tb, hx);             // x last: its sums wait in registers for the barrier
+#endif
         __syncthreads();                                              // every read of Q is done; S_y (A), S_z (B) are complete
         const int off = ltab[(tb * 3 + 0) * NT + opaque_v(tid)];
         if (off != 0xffff) {                                          // Q := S_x
@@ -230,13 +296,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 constexpr int st = decltype(sc_)::value;
                 constexpr int l0 = 2 * st;
                 EXA_STAMP(4);
-#if EXA_M8_SCHED >= 1
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 __syncthreads();
-#if EXA_M8_SCHED >= 1
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 EXA_STAMP(5);
 #ifdef EXA_M8_EARLY_U
                 [[maybe_unused]] double uu[NV];
