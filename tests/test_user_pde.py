@@ -747,3 +747,17 @@ def test_aderdg_manufactured_solution_with_position_and_time():
         errs.append(np.max(np.abs(s.download()[..., 0] - f(x0, x1, 0.1))))
     assert errs[1] < errs[0] / 8 and errs[1] < 2e-4, errs
 
+
+@pytest.mark.gpu
+def test_aderdg_position_dependent_terms_are_refused_where_the_plain_kernel_does_not_fit():
+    """3-D, N = 7: two space-time images exceed LDS -- refused with the reason, not computed without the coordinates"""
+    from exahype_amd import solvers as exa
+    from exahype_amd._lib import ExaHypeHipError
+    p = coupled_xt_ncp_system(max_dim=3)
+    s = exa.AderDgSolver(3, 7, (1, 1, 1), pde=p.register(), n_vars=3)
+    s.upload(1.0 + 0.1 * np.random.default_rng(0).random((1, 1, 1, 7, 7, 7, 3)))
+    with pytest.raises(ExaHypeHipError, match="LDS"):
+        s.step(1e-4)
+    with pytest.raises(ValueError):
+        exa.AderDgSolver(3, 6, (2, 2, 2), pde=p.register(), n_vars=3, one_kernel_step=True)
+
