@@ -223,6 +223,7 @@ struct UserPDE {
         for f in ("dg_inst.hip", "fv_rusanov.hip", "exa_dg_kernels.hpp", "exa_dg_stream.hpp", "exa_dg_reg.hpp", "exa_dg_fused.hpp",
                   "exa_dg_common.hpp", "exa_launch.hpp", "exa_pde.hpp", "exa_dg_plain.hpp", "exa_dg_m8.hpp"):
             h.update(open(os.path.join(CSRC, f), "rb").read())
+        h.update(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "build.py"), "rb").read())      # (compiler flags)
         return h.hexdigest()[:16]
 
     # -- build + registration ----------------------------------------------------------------------
@@ -246,9 +247,10 @@ struct UserPDE {
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         common = [hipcc, "-O3", "-fPIC", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-Wno-unused-function",
                   "-Wno-pass-failed", "-I", CSRC, "-DEXA_PDE_ID=100", '-DEXA_USER_PDE_HEADER="%s"' % hdr]
-        units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"]), ("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2"])]
+        units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"]), ("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2", "-DEXA_UNIT_A"] + _build.DG_SCHED),
+                 ("dg_inst.hip", "dg2b.o", ["-DEXA_DIM=2", "-DEXA_UNIT_B"])]
         if self.max_dim >= 3:
-            units.append(("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3"]))
+            units += [("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3", "-DEXA_UNIT_A"] + _build.DG_SCHED), ("dg_inst.hip", "dg3b.o", ["-DEXA_DIM=3", "-DEXA_UNIT_B"])]
         procs = [(o, subprocess.Popen(common + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(d, o)],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for src, o, extra in units]
         for o, p in procs:
