@@ -1106,7 +1106,11 @@ struct StageBArgs {
     long nc[3];            // local block
     long lo[3], nb[3];     // box origin and extent
     const double* ghost[6];
+    int tiled;             // box slots enumerated tile by tile (every nb[d] a multiple of the tile edge), else lexicographically
 };
+#ifndef EXA_STAGE_B_TILE_SHIFT
+#define EXA_STAGE_B_TILE_SHIFT 3
+#endif
 
 __host__ __device__ constexpr int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
@@ -1150,12 +1154,22 @@ dg_stage_b_kernel(double* __restrict__ u, const double* __restrict__ trace, Stag
         long b = b0 + c;
         if (b >= nbox) b = nbox - 1;
         long cz = 0, cy, cx;
-        if constexpr (DIM == 3) {
-            cz = b % A.nb[2];
-            b /= A.nb[2];
+        if (DIM == 3 && A.tiled) {
+            constexpr int TSH = EXA_STAGE_B_TILE_SHIFT, TM = (1 << TSH) - 1;
+            const long t = b >> (3 * TSH);
+            const int w = (int)(b & ((1 << (3 * TSH)) - 1));
+            const long tz = A.nb[2] >> TSH, ty = A.nb[1] >> TSH;
+            cz = ((t % tz) << TSH) + (w & TM);
+            cy = (((t / tz) % ty) << TSH) + ((w >> TSH) & TM);
+            cx = ((t / (tz * ty)) << TSH) + (w >> (2 * TSH));
+        } else {
+            if constexpr (DIM == 3) {
+                cz = b % A.nb[2];
+                b /= A.nb[2];
+            }
+            cy = b % A.nb[1];
+            cx = b / A.nb[1];
         }
-        cy = b % A.nb[1];
-        cx = b / A.nb[1];
         cc[0] = A.lo[0] + cx;
         cc[1] = A.lo[1] + cy;
         cc[2] = (DIM == 3) ? A.lo[2] + cz : 0;
@@ -1270,12 +1284,22 @@ dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace
         long b = b0 + c;
         if (b >= nbox) b = nbox - 1;
         long cz = 0, cy, cx;
-        if constexpr (DIM == 3) {
-            cz = b % A.nb[2];
-            b /= A.nb[2];
+        if (DIM == 3 && A.tiled) {
+            constexpr int TSH = EXA_STAGE_B_TILE_SHIFT, TM = (1 << TSH) - 1;
+            const long t = b >> (3 * TSH);
+            const int w = (int)(b & ((1 << (3 * TSH)) - 1));
+            const long tz = A.nb[2] >> TSH, ty = A.nb[1] >> TSH;
+            cz = ((t % tz) << TSH) + (w & TM);
+            cy = (((t / tz) % ty) << TSH) + ((w >> TSH) & TM);
+            cx = ((t / (tz * ty)) << TSH) + (w >> (2 * TSH));
+        } else {
+            if constexpr (DIM == 3) {
+                cz = b % A.nb[2];
+                b /= A.nb[2];
+            }
+            cy = b % A.nb[1];
+            cx = b / A.nb[1];
         }
-        cy = b % A.nb[1];
-        cx = b / A.nb[1];
         cc[0] = A.lo[0] + cx;
         cc[1] = A.lo[1] + cy;
         cc[2] = (DIM == 3) ? A.lo[2] + cz : 0;

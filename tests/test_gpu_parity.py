@@ -192,6 +192,30 @@ def test_dg_stage_a_and_step_vs_oracle(exa, orc, dim, N, nc, n_it):
     assert rel_err(s.download().reshape(-1), uo) < TOL
 
 
+@pytest.mark.parametrize("N,nc,box", [(3, (8, 16, 8), None), (6, (8, 8, 8), None), (4, (16, 8, 24), ((8, 0, 8), (16, 8, 24))), (8, (8, 8, 8), None)])
+def test_dg_stage_b_tile_order_vs_oracle(exa, orc, N, nc, box):
+    """stage B enumerates the cells of a box in 8^3 tiles where every extent is a multiple of 8 (dg_inst.hip launch_b): dense (Nf = 9, 36) and
+    segmented-shuffle (Nf = 16, 64) kernels, a whole block and a sub-box whose extents are multiples of 8 beside one that is not"""
+    dim = 3
+    ops = _ops(N)
+    u = euler_dg_state(tuple(nc) + (N,) * dim, seed=900 + N)
+    dx = [1.0 / c for c in nc]
+    dt = 0.02 * min(dx) / (2 * N - 1)
+    s = exa.AderDgSolver(dim, N, nc, dx=dx)
+    s.upload(u)
+    s.predictor_volume(dt)
+    us_o, tr_o = orc.aderdg_stage_a(u.reshape(-1), dt, dx, ops, dim, N, 5, orc.PDE_EULER, N)
+    if box is None:
+        s.riemann_corrector(dt)
+    else:                                                             # the tiled sub-box first, the rest of the block lexicographically
+        lo, hi = box
+        s.riemann_corrector(dt, lo, hi)
+        s.riemann_corrector(dt, (0, 0, 0), (lo[0], nc[1], nc[2]))
+        s.riemann_corrector(dt, (lo[0], 0, 0), (hi[0], nc[1], lo[2]))
+    un_o = orc.aderdg_stage_b(us_o, tr_o, dt, dx, ops, dim, N, 5, orc.PDE_EULER, nc)
+    assert rel_err(s.download().reshape(-1), un_o) < TOL
+
+
 def test_dg_box_launches_cover_block(exa, orc):
     """stage A / stage B over disjoint boxes == one launch over the block."""
     dim, N, nc = 3, 4, (4, 3, 5)
