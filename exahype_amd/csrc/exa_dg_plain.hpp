@@ -3,8 +3,8 @@
 // -- the hooks the reference's harness declares for its kernel (`Unit test/correctness_test.cpp:16-41,145-155`: flux / ncp / source /
 // eigenvalue with (Q, x, h, t, dt, ...)); no ADER-DG counterpart in the reference.
 //
-// A PLAIN kernel: one workgroup per cell, two space-time images (iterate, right-hand side) and u in LDS, every thread loops over space-time
-// nodes and evaluates the flux at the N nodes of each pencil itself (N-fold redundant flux evaluations).  It serves generated term sets
+// A PLAIN kernel: one workgroup per cell, two space-time images (iterate; flux of the current direction, then the right-hand side) and u in
+// LDS, every thread loops over space-time nodes: per direction the flux once per node, then the derivative sums.  It serves generated term sets
 // (pde_codegen.SympyPDE) only; the built-in term sets never come here and their kernels carry none of this.  Not tuned -- correctness and
 // the same data layouts (u*, traces) as the other stage-A kernels, so that stage B and the sharded step work unchanged.
 //
@@ -70,61 +70,96 @@ dg_stage_a_plain_kernel(const double* u_in, double* u_out, double* __restrict__ 
     for (int e = tid; e < N * NN * NV; e += NT) A[e] = U[e % (NN * NV)];
     __syncthreads();
 
-    // right-hand side of one space-time node: flux divergence (+ B . grad q) - source; `grad` also feeds the time average of the ncp term
-    auto rhs_of = [&](int l, int n, const double* x, double tl, double* rhs, double* ncp_sum) {
+    // B . grad q of one space-time node (grad = D q / h along each direction), summed over the directions
+    auto ncp_of = [&](int l, int n, const double* x, double tl, double* out) {
         const double* ql = A + ((long)l * NN + n) * NV;
 #pragma unroll
-        for (int v = 0; v < NV; v++) { rhs[v] = 0.0; ncp_sum[v] = 0.0; }
-        for (int a = 0; a < DIM; a++) {
-            const int ia = digit(n, a);
-            double grad[NV];
+        for (int v = 0; v < NV; v++) out[v] = 0.0;
+        if constexpr (pde_has_ncp<PDE>::value) {
+            for (int a = 0; a < DIM; a++) {
+                const int ia = digit(n, a);
+                double grad[NV], o1[NV];
 #pragma unroll
-            for (int v = 0; v < NV; v++) grad[v] = 0.0;
-            for (int j = 0; j < N; j++) {
-                const int m = n + (j - ia) * stride(a);
-                const double* qj = A + ((long)l * NN + m) * NV;
-                double xj[3] = {x[0], x[1], x[2]};
-                xj[a] = geo.x0[a] + ((double)cc[a] + geo.xi[j]) * geo.h[a];
-                double F[NV];
+                for (int v = 0; v < NV; v++) { grad[v] = 0.0; o1[v] = 0.0; }
+                for (int j = 0; j < N; j++) {
+                    const double* qj = A + ((long)l * NN + n + (j - ia) * stride(a)) * NV;
+                    const double dij = ops.D[ia * N + j] * idx[a];
 #pragma unroll
-                for (int v = 0; v < NV; v++) F[v] = 0.0;
-                fv_flux<PDE>(qj, xj, tl, a, F);
-                const double dij = ops.D[ia * N + j] * idx[a];
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    rhs[v] += dij * F[v];
-                    grad[v] += dij * qj[v];
+                    for (int v = 0; v < NV; v++) grad[v] += dij * qj[v];
                 }
+                fv_ncp<PDE>(ql, grad, x, tl, a, o1);
+#pragma unroll
+                for (int v = 0; v < NV; v++) out[v] += o1[v];
             }
-            if constexpr (pde_has_ncp<PDE>::value) {
-                double out[NV];
-#pragma unroll
-                for (int v = 0; v < NV; v++) out[v] = 0.0;
-                fv_ncp<PDE>(ql, grad, x, tl, a, out);
-#pragma unroll
-                for (int v = 0; v < NV; v++) ncp_sum[v] += out[v];
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < NV; v++) rhs[v] += ncp_sum[v];
-        if constexpr (pde_has_source<PDE>::value) {
-            double Sq[NV];
-#pragma unroll
-            for (int v = 0; v < NV; v++) Sq[v] = 0.0;
-            fv_source<PDE>(ql, x, tl, Sq);
-#pragma unroll
-            for (int v = 0; v < NV; v++) rhs[v] -= Sq[v];
         }
     };
 
+    // Picard iterations.  Per direction: the flux of every space-time node into B (ONE evaluation per node and direction), then each thread
+    // adds the derivative along that direction to the right-hand sides of its nodes (registers); the complete right-hand sides go back
+    // into B for the time update.
+    constexpr int KE = (N * NN + NT - 1) / NT;
     for (int it = 0; it < n_it; it++) {
-        for (int e = tid; e < N * NN; e += NT) {
-            const int l = e / NN, n = e - l * NN;
-            double x[3], rhs[NV], ncps[NV];
-            coords(n, x);
-            rhs_of(l, n, x, geo.t + geo.xi[l] * dt, rhs, ncps);
+        double rhs[KE][NV];
 #pragma unroll
-            for (int v = 0; v < NV; v++) B[(long)e * NV + v] = rhs[v];
+        for (int k = 0; k < KE; k++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) rhs[k][v] = 0.0;
+        for (int a = 0; a < DIM; a++) {
+#pragma unroll
+            for (int k = 0; k < KE; k++) {
+                const int e = tid + k * NT;
+                if (e < N * NN) {
+                    const int l = e / NN, n = e - l * NN;
+                    double x[3], F[NV];
+                    coords(n, x);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) F[v] = 0.0;
+                    fv_flux<PDE>(A + (long)e * NV, x, geo.t + geo.xi[l] * dt, a, F);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) B[(long)e * NV + v] = F[v];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KE; k++) {
+                const int e = tid + k * NT;
+                if (e < N * NN) {
+                    const int l = e / NN, n = e - l * NN, ia = digit(n, a);
+                    for (int j = 0; j < N; j++) {
+                        const double dij = ops.D[ia * N + j] * idx[a];
+                        const double* Fj = B + ((long)l * NN + n + (j - ia) * stride(a)) * NV;
+#pragma unroll
+                        for (int v = 0; v < NV; v++) rhs[k][v] += dij * Fj[v];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < KE; k++) {
+            const int e = tid + k * NT;
+            if (e < N * NN) {
+                const int l = e / NN, n = e - l * NN;
+                const double tl = geo.t + geo.xi[l] * dt;
+                double x[3];
+                coords(n, x);
+                if constexpr (pde_has_ncp<PDE>::value) {
+                    double o1[NV];
+                    ncp_of(l, n, x, tl, o1);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) rhs[k][v] += o1[v];
+                }
+                if constexpr (pde_has_source<PDE>::value) {
+                    double Sq[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; v++) Sq[v] = 0.0;
+                    fv_source<PDE>(A + (long)e * NV, x, tl, Sq);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) rhs[k][v] -= Sq[v];
+                }
+#pragma unroll
+                for (int v = 0; v < NV; v++) B[(long)e * NV + v] = rhs[k][v];
+            }
         }
         __syncthreads();
         for (int e = tid; e < N * NN; e += NT) {
@@ -168,8 +203,8 @@ dg_stage_a_plain_kernel(const double* u_in, double* u_out, double* __restrict__ 
 #pragma unroll
             for (int v = 0; v < NV; v++) qb[v] += ops.w[l] * ql[v];
             if constexpr (pde_has_ncp<PDE>::value) {
-                double rhs[NV], ncps[NV];
-                rhs_of(l, n, x, tl, rhs, ncps);                          // (only its ncp part is used here)
+                double ncps[NV];
+                ncp_of(l, n, x, tl, ncps);
 #pragma unroll
                 for (int v = 0; v < NV; v++) pw[v] -= ops.w[l] * ncps[v];
             }
