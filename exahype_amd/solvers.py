@@ -264,6 +264,12 @@ class AderDgSolver:
     With `part` (CartesianPartition) the block is one shard of a periodic global
     grid: stage A runs on the boundary shell first, the face traces travel over
     RCCL on a second stream while the interior cells run stage A, stage B follows.
+
+    stage_a          "auto" | "lds" | "reg": which stage-A kernel serves 3-D N = 6 / N = 8 (include/exahype_hip.h EXA_STAGE_A_*)
+    one_kernel_step  True: Riemann solve + corrector of a step run in front of the next step's predictor (3-D, N = 6, "reg"); step() then
+                     leaves the corrector pending and reading `u` applies it.  Measured equal to two kernels: off by default.
+    origin, time     physical coordinates of the GLOBAL grid's origin and the start time: only term sets whose terms depend on position /
+                     time see them (pde_codegen.SympyPDE with flux(q, x, t, d) ...); step() advances `time`.
     """
 
     STAGE_A = {"auto": 0, "lds": 1, "reg": 2}      # include/exahype_hip.h EXA_STAGE_A_*
