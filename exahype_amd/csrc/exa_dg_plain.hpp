@@ -8,7 +8,7 @@
 // (pde_codegen.SympyPDE) only; the built-in term sets never come here and their kernels carry none of this.  Not tuned -- correctness and
 // the same data layouts (u*, traces) as the other stage-A kernels, so that stage B and the sharded step work unchanged.
 //
-// Scheme (oracle/aderdg_numpy.py step_xt): node x = origin + (cell + xi_i) h, level time t_l = t + xi_l dt;
+// Scheme (restated in numpy for the tests: step_xt): node x = origin + (cell + xi_i) h, level time t_l = t + xi_l dt;
 //   predictor   S_l = sum_a [ D F_a(q_l, x, t_l) + B_a(q_l, x, t_l) (D q_l) ] / h_a - S(q_l, x, t_l),   q_l' <- u - dt sum_l T[l'][l] S_l
 //   averages    qbar, Fbar_a over the levels; the non-conservative term and the source enter u* point-wise:
 //               u* = u + volume(Fbar) - dt sum_l w_l sum_a B_a(q_l)(D q_l)/h_a + dt sum_l w_l S(q_l)
