@@ -33,7 +33,9 @@ template <int N, class PDE, int TX, int TY> struct FusedSingle {
     // and the store are plain copies, and a 32-lane group of x-pencil tasks -- N pencils x 32 / N cells -- reads distinct banks: the lanes
     // of a cell are NV apart, cells whose slots differ mod 8 sit on the 8 multiples of 4; the lane order pairs the tile's cell rows (0, 2)
     // and (1, 3) for that.  (The y pencils of a cell are N NV = 20 apart, multiples of 4 like the cells: still 4-way.  A row pitch of N + 1
-    // nodes makes them conflict-free too, but the image then no longer leaves room for three workgroups per CU: 0.243 against 0.204 ms.)
+    // nodes makes them conflict-free too, but the image then no longer leaves room for three workgroups per CU: 0.243 against 0.204 ms; the four
+    // padding doubles of a cell spread one behind each row -- row stride 21, same size -- frees them as well but costs more in the copies,
+    // whose odd rows lose their 16-byte alignment: 0.177 against 0.170 ms.)
     static constexpr int RS = N * NV;                           // row stride
     static constexpr int CSP = N * RS + ((4 - (N * RS) % 8) + 8) % 8;
     static constexpr int LCS = LX * LY - 4;                     // cell slots
