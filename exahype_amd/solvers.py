@@ -44,10 +44,12 @@ class FVRusanovKernel:
         self._plan = h
         self.count = self.lib.exa_fv_q_count(h)
 
-    def time_step(self, Q, dt, h=1.0, slot=None):
+    def time_step(self, Q, dt, h=1.0, slot=None, t=0.0, centres=None):
         """In place.  numpy array -> staged through HBM by the library; CUDA tensor -> no copies.
         slot (CUDA int64 tensor, one entry per patch): patches with a negative entry are skipped -- for patch arrays
-        whose number of entries in use is known on the device only."""
+        whose number of entries in use is known on the device only.
+        centres ([n_patches][dim], CUDA tensor or array) and t: the patch centres and the time for term sets whose terms depend on position /
+        time (CUDA Q only; default: every patch centred at the origin, t = 0)."""
         if isinstance(Q, np.ndarray):
             if Q.dtype != np.float64 or not Q.flags.c_contiguous or Q.size != self.count:
                 raise ValueError("Q must be a C-contiguous float64 array of %d entries" % self.count)
@@ -61,6 +63,16 @@ class FVRusanovKernel:
                 raise ValueError("slot must be a contiguous int64 CUDA tensor with one entry per patch")
             check(self.lib.exa_fv_time_step_device_masked(self._plan, C.c_void_p(Q.data_ptr()), C.c_void_p(slot.data_ptr()),
                                                           dt, h, _stream_ptr()))
+            return Q
+        if centres is not None or t != 0.0:
+            cen = None
+            if centres is not None:
+                cen = centres if isinstance(centres, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(centres), dtype=torch.float64).to(Q.device)
+                dim = len(self.shape) - 2
+                if not (cen.is_cuda and cen.dtype == torch.float64 and cen.is_contiguous() and cen.numel() == self.shape[0] * dim):
+                    raise ValueError("centres must be a contiguous float64 CUDA tensor [n_patches][dim]")
+            check(self.lib.exa_fv_time_step_device_at(self._plan, C.c_void_p(Q.data_ptr()), C.c_void_p(cen.data_ptr()) if cen is not None else None,
+                                                      t, dt, h, _stream_ptr()))
             return Q
         check(self.lib.exa_fv_time_step_device(self._plan, C.c_void_p(Q.data_ptr()), dt, h, _stream_ptr()))
         return Q
@@ -579,7 +591,9 @@ class FVPatchGrid:
     condition when asked."""
 
     def __init__(self, dim, grid, patch_size, halo_size=1, n_real=5, n_aux=0, pde=PDE_EULER, mode=FV_RUSANOV,
-                 length=1.0, device=0, boundary=None):
+                 length=1.0, device=0, boundary=None, origin=None, time=0.0):
+        """origin, time: physical coordinates of the grid's low corner and the start time -- reach term sets whose terms depend on position /
+        time (the patch centres follow from them); step() / run() advance the time."""
         torch = _torch()
         self.dim, self.grid, self.P, self.H = dim, tuple(int(g) for g in grid), patch_size, halo_size
         self.n_real, self.n_aux, self.pde = n_real, n_aux, pde
@@ -589,8 +603,11 @@ class FVPatchGrid:
         S = patch_size + 2 * halo_size
         self.Q = torch.zeros(self.grid + (S,) * dim + (n_real + n_aux,), dtype=torch.float64,
                              device=torch.device("cuda", device))
-        self.time = 0.0
+        self.time = float(time)
         self.boundary = boundary                                      # None: periodic
+        og = [float(x) for x in (origin if origin is not None else [0.0] * dim)]
+        idx = np.stack(np.meshgrid(*[np.arange(g) for g in self.grid], indexing="ij"), axis=-1).reshape(-1, dim)
+        self.centres = torch.as_tensor(np.asarray(og)[None, :] + (idx + 0.5) * patch_size * self.h, dtype=torch.float64).to(self.Q.device).contiguous()
 
     def fill_halos(self):
         if self.boundary is None:
@@ -623,7 +640,7 @@ class FVPatchGrid:
 
     def step(self, dt):
         self.fill_halos()
-        self.kernel.time_step(self.Q, dt, self.h)
+        self.kernel.time_step(self.Q, dt, self.h, t=self.time, centres=self.centres)
         self.time += dt
 
     def run(self, t_end, cfl=0.4, max_steps=1000000):
@@ -631,7 +648,7 @@ class FVPatchGrid:
         while self.time < t_end * (1 - 1e-14) and steps < max_steps:
             self.fill_halos()
             dt = min(cfl * self.h / (self.dim * self.max_eigenvalue()), t_end - self.time)
-            self.kernel.time_step(self.Q, dt, self.h)
+            self.kernel.time_step(self.Q, dt, self.h, t=self.time, centres=self.centres)
             self.time += dt
             steps += 1
         return steps

@@ -103,6 +103,10 @@ int exa_fv_time_step_device_masked(exa_fv_plan* plan, double* Q_dev, const long*
  * exahype2::fv::getVolumeCentre: centre - P h / 2 + (index + 1/2) h. */
 int exa_fv_time_step_device_oop(exa_fv_plan* plan, const double* QIn_dev, double* QOut_dev, const double* centre_dev, double t,
                                 double dt, double h, void* stream);
+/* The in-place update WITH the patch centres and the time (same meaning as for exa_fv_time_step_device_oop): what a host driver that keeps
+ * Q with halo resident (halo fill -> update -> ...) calls for term sets whose terms depend on position / time.  exa_fv_time_step_device
+ * is this call with every patch centred at the origin and t = 0. */
+int exa_fv_time_step_device_at(exa_fv_plan* plan, double* Q_dev, const double* centre_dev, double t, double dt, double h, void* stream);
 long exa_fv_qout_count(const exa_fv_plan* plan);
 
 /* ---- ADER-DG cell kernels ---------------------------------------------------- */

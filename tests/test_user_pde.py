@@ -500,6 +500,39 @@ def test_cell_data_flavour_position_and_time_dependent_terms_vs_numpy(dim, P):
 
 
 @pytest.mark.gpu
+def test_fv_host_driver_hands_patch_centres_and_time_to_the_terms():
+    """FVPatchGrid (halo fill -> in-place update) with a term set that sees position and time: the in-place call carries the
+    patch centres of the grid and the running time (exa_fv_time_step_device_at) -- two steps == the out-of-place call on the same filled array"""
+    import torch
+    from exahype_amd import solvers as exa
+    p = variable_coefficient_system(max_dim=2)
+    grid, P, H = (3, 2), 4, 1
+    fv = exa.FVPatchGrid(2, grid, P, H, 2, 0, p.register(), exa.FV_RUSANOV, length=1.5, origin=[0.2, -0.4], time=0.3)
+    rng = np.random.default_rng(3)
+    fv.set_interior(1.0 + 0.3 * rng.random(grid + (P, P, 2)))
+    kern = exa.FVRusanovKernel(2, P, H, 2, 0, 6, pde=p.register(), mode=exa.FV_RUSANOV)
+    h = 1.5 / (3 * P)
+    assert abs(fv.h - h) < 1e-15
+    idx = np.stack(np.meshgrid(np.arange(3), np.arange(2), indexing="ij"), axis=-1).reshape(-1, 2)
+    centres = np.array([0.2, -0.4])[None, :] + (idx + 0.5) * P * h
+    assert np.allclose(fv.centres.cpu().numpy(), centres, atol=1e-15)
+    t = 0.3
+    for dt in (1e-3, 2e-3):
+        fv.fill_halos()
+        want = kern.time_step_oop(fv.Q.reshape((6,) + fv.Q.shape[2:]).clone(), dt, h, t=t, centres=torch.as_tensor(centres, device="cuda"))
+        fv.step(dt)
+        t += dt
+        assert np.max(np.abs(fv.interior().reshape(want.shape) - want.cpu().numpy())) < 1e-13
+    assert abs(fv.time - t) < 1e-15
+    # the terms really see the grid's coordinates: the same grid at the origin gives something else
+    fv0 = exa.FVPatchGrid(2, grid, P, H, 2, 0, p.register(), exa.FV_RUSANOV, length=1.5)
+    fv0.set_interior(1.0 + 0.3 * np.random.default_rng(3).random(grid + (P, P, 2)))
+    fv0.step(1e-3)
+    fv0.step(2e-3)
+    assert np.max(np.abs(fv0.interior() - fv.interior())) > 1e-6
+
+
+@pytest.mark.gpu
 def test_cell_data_flavour_manufactured_source():
     """A state that is constant in space with S = (x0 cos t, 1 + x1): the Rusanov update is forward Euler in time, so after K steps
     q0 = 1 + x0 * sum_k dt cos(t_k), q1 = 2 + K dt (1 + x1) in every volume, to rounding -- position and time reach the term set."""
