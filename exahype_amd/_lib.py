@@ -19,6 +19,7 @@ SIGNATURES = {
     "exa_last_error": (C.c_char_p, []),
     "exa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "exa_register_pde": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "exa_pde_flags": (C.c_int, [C.c_int]),
     "exa_pde_eval_device": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _vp, _vp, _vp, _vp]),
     "exa_fv_plan_create": (C.c_int, [C.c_int] * 7 + [C.c_long, C.c_int, C.POINTER(_vp)]),
     "exa_fv_plan_destroy": (C.c_int, [_vp]),

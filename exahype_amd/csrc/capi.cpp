@@ -40,6 +40,7 @@ struct UserPde {
     void* handle;
     const DgLaunchTable* dg[4];
     int nv;
+    int flags;             // EXA_PDE_FLAG_*
     int (*fv)(int, int, int, int, int, int, long, double*, double, double, const long*, void*, double*, const double*, double);
     int (*ev)(int, long, int, const double*, double*, double*, void*);
 };
@@ -128,9 +129,16 @@ int exa_register_pde(const char* library_path, int* pde_id) {
     u.ev = (decltype(u.ev))dlsym(h, "exa_user_pde_eval");
     if (!nvf || (!u.dg[2] && !u.dg[3] && !u.fv)) { dlclose(h); set_error("%s exports no exahype_amd PDE entry points", library_path); return EXA_ERR_INVALID; }
     u.nv = nvf();
+    int (*flf)() = (int (*)())dlsym(h, "exa_user_pde_flags");
+    u.flags = flf ? flf() : 0;
     g_user.push_back(u);
     *pde_id = 100 + (int)g_user.size() - 1;
     return EXA_OK;
+}
+
+int exa_pde_flags(int pde) {
+    if (pde >= 100) return (pde - 100 < (int)g_user.size()) ? g_user[pde - 100].flags : 0;
+    return 0;
 }
 
 int exa_pde_eval_device(int pde, int normal, long n, int stride, const double* Q_dev, double* F_dev, double* lambda_dev,

@@ -828,6 +828,8 @@ static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double*
 }  // namespace exa
 // user-PDE side library: the same fused kernel instantiated for exa::UserPDE
 extern "C" int exa_user_nv() { return exa::UserPDE::NV; }
+// bit 0: the terms depend on position / time (HAS_XT), bit 1: the term set carries a non-conservative product (HAS_NCP)
+extern "C" int exa_user_pde_flags() { return (exa::pde_has_xt<exa::UserPDE>::value ? 1 : 0) | (exa::pde_has_ncp<exa::UserPDE>::value ? 2 : 0); }
 extern "C" int exa_user_fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
                                   double h, const long* slot, void* stream, double* out, const double* centre, double t) {
     using namespace exa;

@@ -264,6 +264,14 @@ class HaloExchange:
         return arr
 
 
+def _no_coordinates_here(lib, pde):
+    """The CFL scans evaluate eigenvalues without coordinates: refuse term sets whose terms depend on position / time rather than scan them at
+    x = 0, t = 0 (include/exahype_hip.h EXA_PDE_FLAG_XT) -- give step() a dt from a bound of the wave speed instead."""
+    if lib.exa_pde_flags(int(pde)) & 1:
+        raise NotImplementedError("max_eigenvalue / run(): this term set depends on position / time and the eigenvalue scan carries no "
+                                  "coordinates; call step(dt) with a dt from a bound of its wave speed")
+
+
 # ----------------------------------------------------------------------------------------------
 # ADER-DG solver on a regular Cartesian block
 # ----------------------------------------------------------------------------------------------
@@ -437,6 +445,7 @@ class AderDgSolver:
 
     def max_eigenvalue(self):
         torch = _torch()
+        _no_coordinates_here(self.lib, self.pde)
         out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         check(self.lib.exa_dg_max_eigenvalue(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(out.data_ptr()), _stream_ptr()))
         return out
@@ -629,6 +638,7 @@ class FVPatchGrid:
     def max_eigenvalue(self):
         lib = _lib.load()
         torch = _torch()
+        _no_coordinates_here(lib, self.pde)
         flat = self.Q.reshape(-1, self.n_real + self.n_aux)
         lam = torch.zeros(flat.shape[0], dtype=torch.float64, device=self.Q.device)
         best = 0.0

@@ -69,6 +69,12 @@ int exa_device_count(int* count);
  * Here a user term set is a side library generated from SymPy expressions and compiled with hipcc
  * (exahype_amd/pde_codegen.py); registering it yields a pde id >= 100 usable wherever EXA_PDE_* is. */
 int exa_register_pde(const char* library_path, int* pde_id);
+/* What a registered term set carries (0 for the built-in ones): EXA_PDE_FLAG_XT -- its terms depend on position / time (they see the
+ * coordinates the kernels hand them; exa_pde_eval_device and exa_dg_max_eigenvalue, which have none, evaluate them at x = 0, t = 0);
+ * EXA_PDE_FLAG_NCP -- it carries a non-conservative product. */
+#define EXA_PDE_FLAG_XT 1
+#define EXA_PDE_FLAG_NCP 2
+int exa_pde_flags(int pde);
 
 /* ---- point-wise PDE terms (Functions.h:2-3) ---------------------------------- */
 /* For n states Q_dev[n][stride] and a normal: F_dev[n][stride] (first n_flux

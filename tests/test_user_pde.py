@@ -524,6 +524,10 @@ def test_fv_host_driver_hands_patch_centres_and_time_to_the_terms():
         t += dt
         assert np.max(np.abs(fv.interior().reshape(want.shape) - want.cpu().numpy())) < 1e-13
     assert abs(fv.time - t) < 1e-15
+    # the CFL scan carries no coordinates: refused for such a term set, not evaluated at x = 0, t = 0
+    with pytest.raises(NotImplementedError):
+        fv.max_eigenvalue()
+    assert exa._lib.load().exa_pde_flags(p.register()) == 1 and exa._lib.load().exa_pde_flags(exa.PDE_EULER) == 0
     # the terms really see the grid's coordinates: the same grid at the origin gives something else
     fv0 = exa.FVPatchGrid(2, grid, P, H, 2, 0, p.register(), exa.FV_RUSANOV, length=1.5)
     fv0.set_interior(1.0 + 0.3 * np.random.default_rng(3).random(grid + (P, P, 2)))
@@ -717,6 +721,12 @@ def test_aderdg_position_time_and_ncp_vs_numpy_oracle(dim, N, nc, with_ncp, with
             t += dt * (1 + 0.1 * k)
         assert abs(s.time - t) < 1e-15
         assert np.max(np.abs(s.download() - ref)) / np.max(np.abs(ref)) < 1e-10, n_picard
+        if with_xt:
+            with pytest.raises(NotImplementedError):
+                s.max_eigenvalue()
+        else:
+            assert float(s.max_eigenvalue()[0]) > 0.0
+        assert s.lib.exa_pde_flags(p.register()) == (1 if with_xt else 0) + (2 if with_ncp else 0)
     # every slot is really in the kernels: the oracle without it is far from what they produced
     for slot in (["ncp"] if with_ncp else []) + (["source"] if with_xt else []):
         o2 = OracleXtPDE(p)
