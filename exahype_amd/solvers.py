@@ -705,6 +705,9 @@ class SubcellLimiter:
         would be 51 GB).  A step with more troubled cells than that is reported by check(): construct the limiter again with a
         larger capacity (capacity=n_cells serves every mask).  Raises if the patch array does not fit the free device memory."""
         torch = _torch()
+        if solver.lib.exa_pde_flags(int(solver.pde)) & 1:
+            raise NotImplementedError("SubcellLimiter: the patch update of the troubled cells carries no coordinates; term sets whose terms depend on "
+                                      "position / time are not served")
         self.s = solver
         self.Ns = 2 * solver.N - 1
         self.patch_doubles = solver.lib.exa_lim_patch_count(solver._plan)
