@@ -53,6 +53,12 @@ class FVRusanovKernel:
         if isinstance(Q, np.ndarray):
             if Q.dtype != np.float64 or not Q.flags.c_contiguous or Q.size != self.count:
                 raise ValueError("Q must be a C-contiguous float64 array of %d entries" % self.count)
+            if centres is not None or t != 0.0:                      # coordinates: staged through a device tensor here
+                torch = _torch()
+                qd = torch.as_tensor(Q).to(torch.device("cuda", self.device))
+                self.time_step(qd, dt, h, slot, t, centres)
+                Q[...] = qd.cpu().numpy()
+                return Q
             check(self.lib.exa_fv_time_step_host(self._plan, Q.ctypes.data_as(C.c_void_p), dt, h))
             return Q
         torch = _torch()

@@ -524,6 +524,12 @@ def test_fv_host_driver_hands_patch_centres_and_time_to_the_terms():
         t += dt
         assert np.max(np.abs(fv.interior().reshape(want.shape) - want.cpu().numpy())) < 1e-13
     assert abs(fv.time - t) < 1e-15
+    # numpy in, with coordinates: staged through the device, the same update
+    fv.fill_halos()
+    qn = np.ascontiguousarray(fv.Q.reshape((6,) + fv.Q.shape[2:]).cpu().numpy())
+    want = kern.time_step_oop(qn.copy(), 1e-3, h, t=t, centres=centres)
+    kern.time_step(qn, 1e-3, h, t=t, centres=centres)
+    assert np.max(np.abs(qn[:, H:H + P, H:H + P] - want)) < 1e-13
     # the CFL scan carries no coordinates: refused for such a term set, not evaluated at x = 0, t = 0
     with pytest.raises(NotImplementedError):
         fv.max_eigenvalue()
