@@ -21,6 +21,7 @@ SIGNATURES = {
     "exa_register_pde": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "exa_pde_flags": (C.c_int, [C.c_int]),
     "exa_pde_eval_device": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _vp, _vp, _vp, _vp]),
+    "exa_pde_eval_device_at": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "exa_fv_plan_create": (C.c_int, [C.c_int] * 7 + [C.c_long, C.c_int, C.POINTER(_vp)]),
     "exa_fv_plan_destroy": (C.c_int, [_vp]),
     "exa_fv_q_count": (C.c_long, [_vp]),

@@ -42,7 +42,7 @@ struct UserPde {
     int nv;
     int flags;             // EXA_PDE_FLAG_*
     int (*fv)(int, int, int, int, int, int, long, double*, double, double, const long*, void*, double*, const double*, double);
-    int (*ev)(int, long, int, const double*, double*, double*, void*);
+    int (*ev)(int, long, int, const double*, double*, double*, void*, const double*, double);
 };
 static std::vector<UserPde> g_user;
 
@@ -51,9 +51,9 @@ int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_a
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].fv) { set_error("pde %d is not registered", pde); return -1; }
     return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, (void*)s, out, centre, t);
 }
-int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s) {
+int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s, const double* X, double t) {
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].ev) { set_error("pde %d is not registered", pde); return -1; }
-    return g_user[pde - 100].ev(normal, n, stride, Q, F, lam, (void*)s);
+    return g_user[pde - 100].ev(normal, n, stride, Q, F, lam, (void*)s, X, t);
 }
 
 const DgLaunchTable* dg_launch_table(int dim, int pde) {
@@ -143,9 +143,14 @@ int exa_pde_flags(int pde) {
 
 int exa_pde_eval_device(int pde, int normal, long n, int stride, const double* Q_dev, double* F_dev, double* lambda_dev,
                         void* stream) {
+    return exa_pde_eval_device_at(pde, normal, n, stride, Q_dev, nullptr, 0.0, F_dev, lambda_dev, stream);
+}
+
+int exa_pde_eval_device_at(int pde, int normal, long n, int stride, const double* Q_dev, const double* x_dev, double t, double* F_dev,
+                           double* lambda_dev, void* stream) {
     if (pde >= 100) {
         if (normal < 0 || normal > 2 || n < 0 || stride < 1 || !Q_dev) { set_error("exa_pde_eval_device: bad argument"); return EXA_ERR_INVALID; }
-        return pde_eval_launch(pde, normal, n, stride, Q_dev, F_dev, lambda_dev, (hipStream_t)stream);
+        return pde_eval_launch(pde, normal, n, stride, Q_dev, F_dev, lambda_dev, (hipStream_t)stream, x_dev, t);
     }
     if (pde < 0 || pde > 2 || normal < 0 || normal > 2 || n < 0 || stride < 1 || !Q_dev) {
         set_error("exa_pde_eval_device: bad argument");
@@ -153,7 +158,7 @@ int exa_pde_eval_device(int pde, int normal, long n, int stride, const double* Q
     }
     if (pde == EXA_PDE_EULER_REF2D && (normal > 1 || stride < 4)) { set_error("EULER_REF2D needs normal < 2 and stride >= 4"); return EXA_ERR_INVALID; }
     if (pde == EXA_PDE_EULER && stride < 5) { set_error("EULER needs stride >= 5"); return EXA_ERR_INVALID; }
-    return pde_eval_launch(pde, normal, n, stride, Q_dev, F_dev, lambda_dev, (hipStream_t)stream);
+    return pde_eval_launch(pde, normal, n, stride, Q_dev, F_dev, lambda_dev, (hipStream_t)stream, x_dev, t);
 }
 
 /* ---- FV ---------------------------------------------------------------------- */

@@ -65,12 +65,14 @@ const DgLaunchTable* dg_launch_table(int dim, int pde);
 // out != nullptr: out of place (QOut halo-less, [patch][P^dim][n_real + n_aux]); centre: [patch][dim] cell centres or nullptr; t: time
 int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
               double h, const long* slot, hipStream_t s, double* out = nullptr, const double* centre = nullptr, double t = 0.0);
-int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
+// X: [n][3] positions (term sets that depend on position / time) or null; t: time
+int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s, const double* X = nullptr,
+                    double t = 0.0);
 
 // user PDE term sets registered at run time (capi.cpp: exa_register_pde), pde ids >= 100
 int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
                    double h, const long* slot, hipStream_t s, double* out, const double* centre, double t);
-int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s);
+int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s, const double* X, double t);
 
 void set_error(const char* fmt, ...);
 

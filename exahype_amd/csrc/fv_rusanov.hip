@@ -721,17 +721,22 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
 
 template <class PDE>
 __global__ void pde_eval_kernel(int normal, long n, int stride, const double* __restrict__ Q, double* __restrict__ F,
-                                double* __restrict__ lam) {
+                                double* __restrict__ lam, const double* __restrict__ X, double t) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // X: [n][3] positions of the states for term sets that depend on position / time (null: the origin)
+    [[maybe_unused]] double x[3] = {0.0, 0.0, 0.0};
+    if constexpr (pde_has_xt<PDE>::value) {
+        if (X) { x[0] = X[i * 3]; x[1] = X[i * 3 + 1]; x[2] = X[i * 3 + 2]; }
+    }
     if (F) {
         double f[MAXV];
 #pragma unroll
         for (int v = 0; v < MAXV; v++) f[v] = 0.0;
-        PDE::flux_rt(&Q[i * stride], normal, f);
+        fv_flux<PDE>(&Q[i * stride], x, t, normal, f);
         for (int v = 0; v < PDE::NFLUX && v < stride; v++) F[i * stride + v] = f[v];
     }
-    if (lam) lam[i] = PDE::maxeig(&Q[i * stride], normal);
+    if (lam) lam[i] = fv_eig<PDE>(&Q[i * stride], x, t, normal);
 }
 
 template <int DIM, class PDE, int MODE>
@@ -842,10 +847,10 @@ extern "C" int exa_user_fv_launch(int mode, int dim, int P, int H, int n_real, i
     set_error("user PDE: no FV kernel for dim %d", dim);
     return -1;
 }
-extern "C" int exa_user_pde_eval(int normal, long n, int stride, const double* Q, double* F, double* lam, void* stream) {
+extern "C" int exa_user_pde_eval(int normal, long n, int stride, const double* Q, double* F, double* lam, void* stream, const double* X, double t) {
     using namespace exa;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL((pde_eval_kernel<UserPDE>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, normal, n, stride, Q, F, lam);
+    hipLaunchKernelGGL((pde_eval_kernel<UserPDE>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, normal, n, stride, Q, F, lam, X, t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("pde_eval launch: %s", hipGetErrorString(e)); return -2; }
     return 0;
@@ -871,13 +876,13 @@ int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_pat
     return -1;
 }
 
-int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s) {
+int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s, const double* X, double t) {
     if (n <= 0) return 0;
-    if (pde >= 100) return user_pde_eval(pde, normal, n, stride, Q, F, lam, s);
+    if (pde >= 100) return user_pde_eval(pde, normal, n, stride, Q, F, lam, s, X, t);
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (pde == 0) hipLaunchKernelGGL((pde_eval_kernel<EulerRef2D>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
-    else if (pde == 1) hipLaunchKernelGGL((pde_eval_kernel<Euler>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
-    else if (pde == 2) hipLaunchKernelGGL((pde_eval_kernel<Advection<1>>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam);
+    if (pde == 0) hipLaunchKernelGGL((pde_eval_kernel<EulerRef2D>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam, X, t);
+    else if (pde == 1) hipLaunchKernelGGL((pde_eval_kernel<Euler>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam, X, t);
+    else if (pde == 2) hipLaunchKernelGGL((pde_eval_kernel<Advection<1>>), grid, dim3(256), 0, s, normal, n, stride, Q, F, lam, X, t);
     else { set_error("unknown pde %d", pde); return -1; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("pde_eval launch: %s", hipGetErrorString(e)); return -2; }

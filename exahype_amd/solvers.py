@@ -270,12 +270,22 @@ class HaloExchange:
         return arr
 
 
-def _no_coordinates_here(lib, pde):
-    """The CFL scans evaluate eigenvalues without coordinates: refuse term sets whose terms depend on position / time rather than scan them at
-    x = 0, t = 0 (include/exahype_hip.h EXA_PDE_FLAG_XT) -- give step() a dt from a bound of the wave speed instead."""
-    if lib.exa_pde_flags(int(pde)) & 1:
-        raise NotImplementedError("max_eigenvalue / run(): this term set depends on position / time and the eigenvalue scan carries no "
-                                  "coordinates; call step(dt) with a dt from a bound of its wave speed")
+def _sees_position_and_time(lib, pde):
+    """include/exahype_hip.h EXA_PDE_FLAG_XT: the CFL scans of such a term set hand the positions of the states and the time to
+    exa_pde_eval_device_at instead of using the coordinate-free reductions."""
+    return bool(lib.exa_pde_flags(int(pde)) & 1)
+
+
+def _max_eigenvalue_at(lib, pde, dim, states, positions, t):
+    """max over the directions and the states [n][V] (CUDA) of the eigenvalue at positions [n][3] and time t; a 1-element CUDA tensor"""
+    torch = _torch()
+    lam = torch.empty(states.shape[0], dtype=torch.float64, device=states.device)
+    best = torch.zeros(1, dtype=torch.float64, device=states.device)
+    for d in range(dim):
+        check(lib.exa_pde_eval_device_at(int(pde), d, states.shape[0], states.shape[1], C.c_void_p(states.data_ptr()),
+                                         C.c_void_p(positions.data_ptr()), float(t), None, C.c_void_p(lam.data_ptr()), _stream_ptr()))
+        best = torch.maximum(best, lam.max().reshape(1))
+    return best
 
 
 # ----------------------------------------------------------------------------------------------
@@ -449,9 +459,25 @@ class AderDgSolver:
                                                 ghosts, larr(lo) if lo is not None else None,
                                                 larr(hi) if hi is not None else None, dt, darr(self.dx), _stream_ptr()))
 
+    def node_positions(self):
+        """[n_cells * N^dim][3] physical coordinates of the nodes (CUDA, cached): origin + (cell + xi_i) dx"""
+        torch = _torch()
+        if getattr(self, "_xnodes", None) is None:
+            xi = torch.as_tensor(self.operators()["xi"], dtype=torch.float64, device=self.dev)
+            shape = tuple(self.nc) + (self.N,) * self.dim
+            X = torch.zeros(shape + (3,), dtype=torch.float64, device=self.dev)
+            for a in range(self.dim):
+                cs, ns = [1] * (2 * self.dim), [1] * (2 * self.dim)
+                cs[a], ns[self.dim + a] = self.nc[a], self.N
+                c = torch.arange(self.nc[a], dtype=torch.float64, device=self.dev).reshape(cs)
+                X[..., a] = self.origin[a] + (c + xi.reshape(ns)) * self.dx[a]
+            self._xnodes = X.reshape(-1, 3).contiguous()
+        return self._xnodes
+
     def max_eigenvalue(self):
         torch = _torch()
-        _no_coordinates_here(self.lib, self.pde)
+        if _sees_position_and_time(self.lib, self.pde):
+            return _max_eigenvalue_at(self.lib, self.pde, self.dim, self.u.reshape(-1, self.nv), self.node_positions(), self.time)
         out = torch.zeros(1, dtype=torch.float64, device=self.dev)
         check(self.lib.exa_dg_max_eigenvalue(self._plan, C.c_void_p(self.u.data_ptr()), C.c_void_p(out.data_ptr()), _stream_ptr()))
         return out
@@ -644,8 +670,18 @@ class FVPatchGrid:
     def max_eigenvalue(self):
         lib = _lib.load()
         torch = _torch()
-        _no_coordinates_here(lib, self.pde)
         flat = self.Q.reshape(-1, self.n_real + self.n_aux)
+        if _sees_position_and_time(lib, self.pde):
+            if getattr(self, "_xvol", None) is None:                   # volume centres of the array with halo (exahype2::fv::getVolumeCentre)
+                S = self.P + 2 * self.H
+                off = (torch.arange(S, dtype=torch.float64, device=self.Q.device) - self.H + 0.5 - 0.5 * self.P) * self.h
+                X = torch.zeros((self.centres.shape[0],) + (S,) * self.dim + (3,), dtype=torch.float64, device=self.Q.device)
+                for a in range(self.dim):
+                    sh = [1] * (1 + self.dim)
+                    sh[1 + a] = S
+                    X[..., a] = self.centres[:, a].reshape((-1,) + (1,) * self.dim) + off.reshape(sh)
+                self._xvol = X.reshape(-1, 3).contiguous()
+            return float(_max_eigenvalue_at(lib, self.pde, self.dim, flat, self._xvol, self.time)[0])
         lam = torch.zeros(flat.shape[0], dtype=torch.float64, device=self.Q.device)
         best = 0.0
         for d in range(self.dim):

@@ -70,7 +70,8 @@ int exa_device_count(int* count);
  * (exahype_amd/pde_codegen.py); registering it yields a pde id >= 100 usable wherever EXA_PDE_* is. */
 int exa_register_pde(const char* library_path, int* pde_id);
 /* What a registered term set carries (0 for the built-in ones): EXA_PDE_FLAG_XT -- its terms depend on position / time (they see the
- * coordinates the kernels hand them; exa_pde_eval_device and exa_dg_max_eigenvalue, which have none, evaluate them at x = 0, t = 0);
+ * coordinates the kernels hand them; exa_pde_eval_device and exa_dg_max_eigenvalue, which have none, evaluate them at x = 0, t = 0:
+ * use exa_pde_eval_device_at for the CFL scan of such a term set, as exahype_amd/solvers.py does);
  * EXA_PDE_FLAG_NCP -- it carries a non-conservative product. */
 #define EXA_PDE_FLAG_XT 1
 #define EXA_PDE_FLAG_NCP 2
@@ -81,6 +82,10 @@ int exa_pde_flags(int pde);
  * entries written) and lambda_dev[n].  Either output may be NULL. */
 int exa_pde_eval_device(int pde, int normal, long n, int stride, const double* Q_dev, double* F_dev,
                         double* lambda_dev, void* stream);
+/* The same with the positions of the states, x_dev [n][3] (NULL: the origin), and the time: for term sets whose terms depend on them
+ * (EXA_PDE_FLAG_XT) -- the CFL scan of a host driver hands the volume centres / node coordinates here. */
+int exa_pde_eval_device_at(int pde, int normal, long n, int stride, const double* Q_dev, const double* x_dev, double t, double* F_dev,
+                           double* lambda_dev, void* stream);
 
 /* ---- Finite-Volume Rusanov patch update (test.h:3) -------------------------- */
 int exa_fv_plan_create(int device, int mode, int dim, int patch_size, int halo_size, int n_real, int n_aux,

@@ -530,9 +530,12 @@ def test_fv_host_driver_hands_patch_centres_and_time_to_the_terms():
     want = kern.time_step_oop(qn.copy(), 1e-3, h, t=t, centres=centres)
     kern.time_step(qn, 1e-3, h, t=t, centres=centres)
     assert np.max(np.abs(qn[:, H:H + P, H:H + P] - want)) < 1e-13
-    # the CFL scan carries no coordinates: refused for such a term set, not evaluated at x = 0, t = 0
-    with pytest.raises(NotImplementedError):
-        fv.max_eigenvalue()
+    # the CFL scan hands the volume centres and the time to the eigenvalue (exa_pde_eval_device_at)
+    npde = NumpyXtPDE(p)
+    xv = _volume_centres(centres, P, H, h, 2)
+    qa = fv.Q.reshape((6,) + fv.Q.shape[2:]).cpu().numpy()
+    want_lam = max(np.max(np.abs(npde.maxeig(qa, xv, fv.time, d))) for d in range(2))
+    assert abs(fv.max_eigenvalue() - want_lam) < 1e-13
     assert exa._lib.load().exa_pde_flags(p.register()) == 1 and exa._lib.load().exa_pde_flags(exa.PDE_EULER) == 0
     # the terms really see the grid's coordinates: the same grid at the origin gives something else
     fv0 = exa.FVPatchGrid(2, grid, P, H, 2, 0, p.register(), exa.FV_RUSANOV, length=1.5)
@@ -727,11 +730,11 @@ def test_aderdg_position_time_and_ncp_vs_numpy_oracle(dim, N, nc, with_ncp, with
             t += dt * (1 + 0.1 * k)
         assert abs(s.time - t) < 1e-15
         assert np.max(np.abs(s.download() - ref)) / np.max(np.abs(ref)) < 1e-10, n_picard
-        if with_xt:
-            with pytest.raises(NotImplementedError):
-                s.max_eigenvalue()
-        else:
-            assert float(s.max_eigenvalue()[0]) > 0.0
+        # the CFL scan: the eigenvalue at the node coordinates and the current time
+        x3 = A._coords(tuple(nc), N, operators(N), dx, origin)
+        un = s.download()
+        want_lam = max(np.max(np.abs(o.maxeig(un, x3, s.time, a) * np.ones(un.shape[:-1]))) for a in range(dim))
+        assert abs(float(s.max_eigenvalue()[0]) - want_lam) < 1e-12
         assert s.lib.exa_pde_flags(p.register()) == (1 if with_xt else 0) + (2 if with_ncp else 0)
     # every slot is really in the kernels: the oracle without it is far from what they produced
     for slot in (["ncp"] if with_ncp else []) + (["source"] if with_xt else []):
