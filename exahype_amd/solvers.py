@@ -339,7 +339,7 @@ class AderDgSolver:
         # The step as ONE kernel (include/exahype_hip.h exa_dg_corrector_predictor; 3-D, N = 6, register-resident stage A): step() leaves
         # the block as (u*, traces) with the corrector PENDING, the next step's kernel applies it in front of its predictor, and reading
         # `u` (download, max_eigenvalue, ...) applies it with the stand-alone stage B first.  Costs a second trace array.  Off by default:
-        # measured EQUAL to the two-kernel step within 1 % (22.2 against 22.1 ms per step at 64^3, profiles/r03_one_kernel_step.txt) --
+        # measured equal to 4 % slower than the two-kernel step (22.2 against 21.4 - 22.1 ms per step at 64^3, profiles/r03_one_kernel_step.txt) --
         # stage B's 2.0 ms are traded for a prologue of 0.8 ms of arithmetic + 0.9 ms of exposed trace-load latency + two barriers.
         has = bool(self.lib.exa_dg_has_corrector_predictor(h))
         if one_kernel_step and not has:
