@@ -94,6 +94,30 @@ def synthetic_state(solver, part_coords, pdims, seed):
 
 
 # ------------------------------------------------------------------------------------------------------
+# the same Euler system as a USER would hand it over: SymPy expressions (north_star: "a SymPy-specified flux/eigenvalue system drops in")
+# ------------------------------------------------------------------------------------------------------
+def sympy_euler():
+    """3-D compressible Euler (gamma = 1.4) written as plain SymPy expressions -- the arithmetic of the reference's `Flux` / `maxEigenvalue`
+    (Unit test/Functions.cpp:9-62) without any hint about caching, reciprocals or directions; pde_codegen.SympyPDE turns it into the device
+    term set (`other_configs.cfg2_sympy` / `cfg4_sympy` run the benchmark configurations on it)."""
+    import sympy
+    from exahype_amd.pde_codegen import SympyPDE
+
+    def pressure(q):
+        return sympy.Float(0.4) * (q[4] - (q[1] ** 2 + q[2] ** 2 + q[3] ** 2) / (2 * q[0]))
+
+    def flux(q, d):
+        p, un = pressure(q), q[d + 1] / q[0]
+        f = [un * q[0], un * q[1], un * q[2], un * q[3], un * (q[4] + p)]
+        f[d + 1] += p
+        return f
+
+    def max_eigenvalue(q, d):
+        return sympy.Abs(q[d + 1] / q[0]) + sympy.sqrt(sympy.Float(1.4) * pressure(q) / q[0])
+    return SympyPDE(5, flux, max_eigenvalue, max_dim=3, name="euler_sympy_bench")
+
+
+# ------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle, timed on the GPU box's host cores; reported, never the target)
 # ------------------------------------------------------------------------------------------------------
 def host_cpu_info():
@@ -221,8 +245,9 @@ def read_traffic(name, **match):
 # ------------------------------------------------------------------------------------------------------
 # configurations
 # ------------------------------------------------------------------------------------------------------
-def run_cfg2(a, torch, exa, world, rank, local):
-    """BASELINE configs[2] / configs[3]: 3-D Euler p=5, full predictor + corrector, 128^3 cells per GPU."""
+def run_cfg2(a, torch, exa, world, rank, local, pde=None):
+    """BASELINE configs[2] / configs[3]: 3-D Euler p=5, full predictor + corrector, 128^3 cells per GPU.  pde: id of a registered (generated)
+    term set instead of the built-in exa::Euler."""
     import torch.distributed as dist
     selfx = world == 1 and a.self_exchange           # rehearsal: the sharded step on one GPU, periodic wrap through RCCL send/recv to self
     part = exa.CartesianPartition(world, rank, 3, exchange_self=(0, 1, 2) if selfx else ()) if (world > 1 or selfx) else None
@@ -232,7 +257,7 @@ def run_cfg2(a, torch, exa, world, rank, local):
     N = a.order + 1
     nc = [a.cells] * 3
     dx = [1.0 / (nc[d] * pdims[d]) for d in range(3)]
-    s = exa.AderDgSolver(3, N, nc, pde=exa.PDE_EULER, n_vars=5, n_picard=-1, dx=dx, device=local, part=part,
+    s = exa.AderDgSolver(3, N, nc, pde=exa.PDE_EULER if pde is None else pde, n_vars=5, n_picard=-1, dx=dx, device=local, part=part,
                          backend_is_gloo=(a.backend != "nccl"))
     lam = synthetic_state(s, coords, pdims, seed=2 + rank)
     dt = 0.1 * min(dx) / ((2 * a.order + 1) * 3 * lam)
@@ -269,7 +294,8 @@ def run_cfg2(a, torch, exa, world, rank, local):
         "config": {"workload": "3D compressible Euler, ADER-DG p=%d, %d^3 cells per GPU (%dx%dx%d process grid), "
                                "%d Picard iterations + volume + Riemann + corrector" % (a.order, a.cells, pdims[0], pdims[1], pdims[2], N),
                    "cells_per_gpu": a.cells ** 3, "order": a.order, "n_vars": 5, "dt": dt,
-                   "parallelism": "cartesian-%dx%dx%d" % tuple(pdims)},
+                   "parallelism": "cartesian-%dx%dx%d" % tuple(pdims),
+                   "term_set": "built-in exa::Euler (exa_pde.hpp)" if pde is None else "generated from SymPy expressions (pde_codegen.SympyPDE)"},
         "finite": finite,
     }
     # stage A: per step one launch (single GPU) or the shell boxes + the interior box (sharded); sum per step
@@ -364,11 +390,11 @@ def run_cfg1(a, torch, exa, local):
     return out
 
 
-def run_cfg4(a, torch, exa, local):
+def run_cfg4(a, torch, exa, local, pde=None):
     """BASELINE configs[4], the per-GPU shape on one GPU: 3-D Euler p=7, 64^3 cells, FV subcell limiter with a Bernoulli(0.05)
     troubled mask (seed 4): troubled cells take the 15^3 FV Rusanov patch update instead of the DG result."""
     N, n = 8, a.cells if a.cells != 128 else 64
-    s = exa.AderDgSolver(3, N, (n,) * 3, device=local)
+    s = exa.AderDgSolver(3, N, (n,) * 3, device=local, **({} if pde is None else {"pde": pde, "n_vars": 5}))
     lam = synthetic_state(s, [0, 0, 0], [1, 1, 1], seed=4)
     dt = 0.1 * min(s.dx) / ((2 * 7 + 1) * 3 * lam)
     g = torch.Generator(device=s.dev)
@@ -396,9 +422,12 @@ def run_cfg4(a, torch, exa, local):
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4] per-GPU shape: 3D compressible Euler, ADER-DG p=7, %d^3 cells, 8 Picard iterations + "
                                   "volume + Riemann + corrector, FV subcell limiter (15^3 patches) on a Bernoulli(0.05) troubled mask" % n,
-                      "cells_per_gpu": n ** 3, "order": 7, "n_vars": 5, "dt": dt, "troubled_cells": int(cnt)},
+                      "cells_per_gpu": n ** 3, "order": 7, "n_vars": 5, "dt": dt, "troubled_cells": int(cnt),
+                      "term_set": "built-in exa::Euler (exa_pde.hpp)" if pde is None else "generated from SymPy expressions (pde_codegen.SympyPDE)"},
            "finite": bool(torch.isfinite(s.u).all().item()),
-           "roofline": {"kernel": s.stage_a_kernel_name(), "bound": "fp64-valu", "bound_basis": "algorithmic flops (SURVEY.md 8(d))",
+           "roofline": {"kernel": s.stage_a_kernel_name(), "bound": "fp64 (valu+mfma)", "bound_basis": "algorithmic flops (SURVEY.md 8(d)); the derivative "
+                        "contraction runs on v_mfma_f64_4x4x4_4b_f64, everything else on the vector ALU -- both pipes have the 78.6 TFLOP/s fp64 peak",
+                        "mfma_busy": 0.126, "busy_source": "profiles/r03_pmc_mfma_n8.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, 32^3 cells; not measured in this run)",
                         "hbm_measured_gbs": (traffic / ta / 1e9) if traffic else None, "achieved": work["flop_a"] / ta / 1e12,
                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": work["flop_a"] / ta / 1e12 / FP64_PEAK_TFLOPS,
                         "frac_of_measured_fma_loop": work["flop_a"] / ta / 1e12 / FP64_MEASURED_TFLOPS, "traffic": traffic,
@@ -463,7 +492,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg1", "cfg4", "fv-ref"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg1", "cfg4", "fv-ref", "cfg2_sympy", "cfg4_sympy"])
     ap.add_argument("--cells", type=int, default=128, help="cells per axis per GPU (default: BASELINE configs[2])")
     ap.add_argument("--order", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -477,7 +506,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if a.config != "cfg2":
+        if a.config not in ("cfg2", "cfg2_sympy"):
             sys.exit("bench.py: --config %s is a single-GPU configuration" % a.config)
         spawn_ranks(a.gpus, sys.argv[1:])                      # does not return
     if a.gpus != world:
@@ -528,16 +557,32 @@ def main():
             b.no_cpu_baseline = True
             b.steps, b.warmup = 3, 1
             others = {}
-            for name, fn in (("cfg1", run_cfg1), ("cfg4", run_cfg4), ("fv-ref", run_fv_ref)):
+            b2 = argparse.Namespace(**vars(b))
+            b2.warmup = 2
+
+            def sympy_id():
+                return sympy_euler().register()                 # (JIT-compiled by hipcc on first use; __graft_entry__.build() prebuilds it in-tree)
+            runs = (("cfg2_sympy", lambda: run_cfg2(b2, torch, exa, 1, 0, local, pde=sympy_id())), ("cfg1", lambda: run_cfg1(b, torch, exa, local)),
+                    ("cfg4", lambda: run_cfg4(b, torch, exa, local)), ("cfg4_sympy", lambda: run_cfg4(b, torch, exa, local, pde=sympy_id())),
+                    ("fv-ref", lambda: run_fv_ref(b, torch, exa, local)))
+            for name, fn in runs:
                 try:
-                    r = fn(b, torch, exa, local)
+                    r = fn()
                     others[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "finite", "roofline")}
                     others[name]["workload"] = r["config"]["workload"]
+                    others[name]["term_set"] = r["config"].get("term_set")
+                    base = out if name == "cfg2_sympy" else others.get("cfg4") if name == "cfg4_sympy" else None
+                    if base and "value" in base:
+                        others[name]["vs_builtin_term_set"] = r["value"] / base["value"]
                 except Exception as e:                                     # a failing side line must not take the headline with it -- it says so
                     others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                 gc.collect()
                 torch.cuda.empty_cache()
             out["other_configs"] = others
+    elif a.config == "cfg2_sympy":
+        out = run_cfg2(a, torch, exa, world, rank, local, pde=sympy_euler().register())
+    elif a.config == "cfg4_sympy":
+        out = run_cfg4(a, torch, exa, local, pde=sympy_euler().register())
     elif a.config == "cfg1":
         out = run_cfg1(a, torch, exa, local)
     elif a.config == "cfg4":

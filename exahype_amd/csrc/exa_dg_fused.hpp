@@ -163,7 +163,7 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
         double F[N][NV], q[N][NV];
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            double a[PDE::NAUX];
+            double a[nz(PDE::NAUX)];
 #pragma unroll
             for (int v = 0; v < NV; v++) q[j][v] = EXA_FLD(&U[p_lc * CSP + p_n0 + j * p_ns + v]);
             PDE::aux_fast(q[j], a);

@@ -210,7 +210,7 @@ __device__ inline void pencil_sums(const double (&qw)[N][PDE::NV], const EXA_AS4
 #pragma unroll
     for (int j = 0; j < H; j++) {
         const int jm = N - 1 - j;
-        double aa[NA], ab[NA], Fa[NV], Fb[NV];
+        double aa[nz(NA)], ab[nz(NA)], Fa[NV], Fb[NV];
         PDE::aux_fast(qw[j], aa);
         PDE::template flux_scaled<D>(qw[j], aa, idx_d, Fa);
         PDE::aux_fast(qw[jm], ab);
@@ -237,7 +237,7 @@ __device__ inline void pencil_sums(const double (&qw)[N][PDE::NV], const EXA_AS4
         }
     }
     if constexpr (N % 2 == 1) {
-        double aa[NA], Fa[NV];
+        double aa[nz(NA)], Fa[NV];
         PDE::aux_fast(qw[H], aa);
         PDE::template flux_scaled<D>(qw[H], aa, idx_d, Fa);
 #pragma unroll
@@ -549,7 +549,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
 #pragma unroll
                     for (int j = 0; j < H; j++) {
                         const int jm = N - 1 - j;                // mirror node
-                        double aa[NA], ab[NA], Fa[NV], Fb[NV];
+                        double aa[nz(NA)], ab[nz(NA)], Fa[NV], Fb[NV];
 #ifndef EXA_A_LOADS_FIRST
                         if constexpr (!WIDE) {
 #pragma unroll
@@ -585,7 +585,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         }
                     }
                     if constexpr (N % 2 == 1) {                  // middle node
-                        double aa[NA], Fa[NV];
+                        double aa[nz(NA)], Fa[NV];
 #ifndef EXA_A_LOADS_FIRST
                         if constexpr (!WIDE) {
 #pragma unroll
@@ -847,7 +847,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                     for (int v = 0; v < NV; v++) qb[v] = Fb[v] = 0.0;
 #pragma unroll
                     for (int l = 0; l < N; l++) {
-                        double a[NA], F[NV];
+                        double a[nz(NA)], F[NV];
 #pragma unroll
                         for (int v = 0; v < NV; v++) q[v] = qn[v];
                         if (l + 1 < N) {
@@ -872,7 +872,7 @@ dg_stage_a_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, d
                         for (int v = 0; v < NV; v++) Fb[v] += wm[l] * F[v];
                     }
                 } else {
-                    double a[NA];
+                    double a[nz(NA)];
                     PDE::aux_fast(ur, a);
 #pragma unroll
                     for (int v = 0; v < NV; v++) qb[v] = ur[v];
@@ -1003,7 +1003,7 @@ dg_stage_a_single_kernel(const double* __restrict__ u_in, double* __restrict__ u
             const int c = task / NN, n = task - c * NN;
             const long cell = cell_id[c];
             const int off = c * CS + G::node_off(n);
-            double a[NA], F[NV];
+            double a[nz(NA)], F[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) ur[k][v] = cell >= 0 ? u_in[(cell * NN + n) * NV + v] : 1.0;
             PDE::aux_fast(ur[k], a);

@@ -116,7 +116,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             // iterations and spill -- 96 B of scratch, reloaded in front of every round)
             const int dj = opaque_v(d_j);
             const int na = off + dj * ps, nb = off + (N - 1 - dj) * ps;
-            double qa[NV], qb[NV], aa[NA], ab[NA], Fa[NV], Fb[NV];
+            double qa[NV], qb[NV], aa[nz(NA)], ab[nz(NA)], Fa[NV], Fb[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 qa[v] = EXA_SLD(na + v * VS);
@@ -154,7 +154,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         // software-pipelined over the three rounds: the LDS loads of the next round are issued in front of the matrix instructions and the
         // stores of the current one (they read Q and the scalars, which no round writes), so their latency and the store queue overlap
         const int t_ = opaque_v(tid), dj = opaque_v(d_j);
-        struct Ops { double qa[NV], qb[NV], aa[NA], ab[NA]; };
+        struct Ops { double qa[NV], qb[NV], aa[nz(NA)], ab[nz(NA)]; };
         auto offs = [&](auto dc, int& na, int& nb) -> bool {
             constexpr int D = decltype(dc)::value;
             const int off = ltab[(tb * 3 + D) * NT + t_];
@@ -239,7 +239,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         __syncthreads();
     };
     auto put_level = [&](int ls, const double (&qv)[NV]) {
-        double a[NA];
+        double a[nz(NA)];
         PDE::aux_fast(qv, a);
 #pragma unroll
         for (int v = 0; v < NV; v++) lds[o_off + ls * SL + v * VS] = qv[v];
@@ -378,7 +378,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             }
 #pragma unroll
             for (int l = 0; l < N; l++) {
-                double a[NA], F[NV];
+                double a[nz(NA)], F[NV];
                 PDE::aux_fast(q[l], a);
 #pragma unroll
                 for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[l][v];

@@ -607,7 +607,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
             }
 #pragma unroll
             for (int l = 0; l < N; l++) {
-                double a[NA], F[NV];
+                double a[nz(NA)], F[NV];
                 PDE::aux_fast(q[l], a);
 #pragma unroll
                 for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[l][v];

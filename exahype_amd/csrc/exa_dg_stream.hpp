@@ -190,7 +190,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                     for (int si = 0; si < SLOTS; si++) {
                         const int ls = OH == 2 ? opaque_s(o_h) : si;
                         if (ls < nl EXA_ABL_COND_LOAD) {
-                            double a[NA];
+                            double a[nz(NA)];
                             const int o_off = base + ls * SL;
                             PDE::aux_fast(nxt[si], a);
 #pragma unroll
@@ -250,7 +250,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                             for (int v = 0; v < NV; v++) mid[v] = 0.0;
 #pragma unroll
                             for (int j = 0; j < H; j++) {
-                                double qa[NV], aa[NA], Fa[NV], qb[NV], ab[NA], Fb[NV];
+                                double qa[NV], aa[nz(NA)], Fa[NV], qb[NV], ab[nz(NA)], Fb[NV];
 #pragma unroll
                                 for (int v = 0; v < NV; v++) {
                                     qa[v] = EXA_SLD(off + v * LG * SL + j * ps);
@@ -285,7 +285,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                                 }
                             }
                             if constexpr (N % 2 == 1) {          // middle node
-                                double qa[NV], aa[NA], Fa[NV];
+                                double qa[NV], aa[nz(NA)], Fa[NV];
 #pragma unroll
                                 for (int v = 0; v < NV; v++) qa[v] = EXA_SLD(off + v * LG * SL + H * ps);
 #pragma unroll
@@ -314,7 +314,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                             for (int v = 0; v < NV; v++) s[i][v] = 0.0;
 #pragma unroll
                         for (int j = 0; j < N; j++) {
-                            double q[NV], a[NA], F[NV];
+                            double q[NV], a[nz(NA)], F[NV];
 #pragma unroll
                             for (int v = 0; v < NV; v++) q[v] = EXA_SLD(off + v * LG * SL + j * ps);
 #pragma unroll
@@ -475,7 +475,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                     for (int k = 0; k < LH; k++) {
                         const int lp = lp0 + k;
                         if (lp < N) {
-                            double a[NA], F[NV];
+                            double a[nz(NA)], F[NV];
                             PDE::aux_fast(acc[k], a);
                             const double wl = wm[lp];
 #pragma unroll
@@ -495,7 +495,7 @@ dg_stage_a_stream_kernel(const double* __restrict__ u_in, double* __restrict__ u
                         }
                     }
                 } else if (o_h == 0) {                           // single stage: qbar = u, Fbar = F(u)
-                    double a[NA];
+                    double a[nz(NA)];
                     PDE::aux_fast(nxt[0], a);
 #pragma unroll
                     for (int v = 0; v < NV; v++) qb[v] = nxt[0][v];

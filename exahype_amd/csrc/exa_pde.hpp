@@ -7,7 +7,7 @@
 // Interface every PDE struct provides:
 //   NV        variables the scheme evolves (n_real)
 //   NFLUX     leading entries of F that flux() writes (rest are left alone)
-//   NAUX      per-node cached scalars shared by the flux in every direction
+//   NAUX      per-node cached scalars shared by the flux in every direction (0 allowed: no LDS slot, arrays sized nz(NAUX))
 //   aux(q, a)                  a[NAUX] from q[NV]   (Euler: 1/rho and p)
 //   flux<d>(q, a, F)           F[NV] for normal d using the cached scalars
 //   flux_scaled<d>(q, a, s, F) s * F[NV] with the scale folded into the two cached scalars
@@ -27,6 +27,9 @@
 namespace exa {
 
 constexpr double GAMMA = 1.4;
+
+// array extent for NAUX cached scalars: a term set may have none (zero-length arrays are not permitted in device code)
+__host__ __device__ constexpr int nz(int n) { return n > 0 ? n : 1; }
 
 // Optional member of a PDE struct: `static constexpr bool HAS_SOURCE = true` with `source(q, S)` = the algebraic source S(q)[NV] of
 // q_t + div F(q) = S(q) (the hook the reference's harness declares next to flux and maxEigenvalue, `Unit test/correctness_test.cpp:16-23`;

@@ -443,7 +443,7 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
     const int plane = S * S * V;                                  // doubles per plane
     const int aplane = S * S * NA;
     const int slotd = slab_slot(S, V);
-    double* auxr = ring + 3 * slotd;                              // [2][S*S][NA]   (CACHE only)
+    double* auxr = ring + 3 * slotd;                              // [2][S*S][nz(NA)]   (CACHE only)
     const int orow = S * V;
     double* Qp = Q + (long)blockIdx.x * S * plane;
     const int tid = threadIdx.x;
@@ -509,7 +509,7 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
     };
 
     // rolling column of this lane: states (and scalars) of (i-1, j, k), (i, j, k); x-face flux between them
-    double qm[NQ], qc[NQ], qp[NQ], am[NA], ac[NA], Fxl[NQ];
+    double qm[NQ], qc[NQ], qp[NQ], am[nz(NA)], ac[nz(NA)], Fxl[NQ];
 #pragma unroll
     for (int v = 0; v < NQ; v++) { qm[v] = 0.0; qc[v] = 0.0; qp[v] = 0.0; Fxl[v] = 0.0; }
 #pragma unroll

@@ -28,17 +28,86 @@ USER_DIR = os.path.join(HERE, "_user")
 
 
 class _DevicePrinter(C99CodePrinter):
-    """C for the device: small integer powers as products, 1/x as a division."""
+    """C for the device: small integer powers as products, 1/x as a division -- or, fast=True (the ADER-DG kernels, tolerance 1e-10), as
+    exa::fast_rcp (v_rcp_f64 + one Newton step, <= 11 ulp) and square roots as exa::fast_sqrt (v_rsq_f64 + two Goldschmidt steps), the
+    sequences the built-in term sets use (exa_pde.hpp)."""
+
+    def __init__(self, fast=False):
+        super().__init__()
+        self.fast = fast
+
+    def _rcp(self, x):
+        return ("exa::fast_rcp(%s)" if self.fast else "(1.0/(%s))") % x
+
+    def _print__Rcp(self, expr):
+        return "exa::fast_rcp(%s)" % self._print(expr.args[0])
+
+    def _print__Sqrt(self, expr):
+        return "exa::fast_sqrt(%s)" % self._print(expr.args[0])
 
     def _print_Pow(self, expr):
         b, e = expr.base, expr.exp
         if e.is_Integer and 2 <= int(e) <= 4:
             return "(" + "*".join(["(%s)" % self._print(b)] * int(e)) + ")"
         if e == -1:
-            return "(1.0/(%s))" % self._print(b)
+            return self._rcp(self._print(b))
         if e.is_Integer and -4 <= int(e) <= -2:
-            return "(1.0/(" + "*".join(["(%s)" % self._print(b)] * (-int(e))) + "))"
+            return self._rcp("*".join(["(%s)" % self._print(b)] * (-int(e))))
+        if self.fast and e == sympy.Rational(1, 2):
+            return "exa::fast_sqrt(%s)" % self._print(b)
+        if self.fast and e == sympy.Rational(-1, 2):
+            return "exa::fast_rcp(exa::fast_sqrt(%s))" % self._print(b)
         return super()._print_Pow(expr)
+
+
+class _Rcp(sympy.Function):
+    """1/x by the fast sequence (printing only)"""
+    nargs = 1
+
+
+class _Sqrt(sympy.Function):
+    nargs = 1
+
+
+def _fast_forms(e):
+    """Negative and half-integer powers as _Rcp / _Sqrt calls, so that the printer never emits an IEEE division (C99CodePrinter prints a
+    product with negative powers as a quotient) and the common-subexpression pass shares the reciprocals."""
+    def conv(p):
+        b, ex = p.base, p.exp
+        if ex.is_Integer and ex < 0:
+            return _Rcp(b ** (-ex))
+        if ex == sympy.Rational(1, 2):
+            return _Sqrt(b)
+        if ex == sympy.Rational(-1, 2):
+            return _Rcp(_Sqrt(b))
+        if ex.is_Rational and ex.q == 2:
+            r = _Sqrt(b) * b ** ((abs(ex.p) - 1) // 2)
+            return r if ex > 0 else _Rcp(r)
+        return p
+    return e.replace(lambda x: x.is_Pow and (x.exp.is_negative or (x.exp.is_Rational and x.exp.q == 2)), conv)
+
+
+def _weighted_ops(e):
+    """Vector-ALU instructions an expression costs, roughly: add / mul / fma-able pair 1, reciprocal or square root 8, other functions 20."""
+    if e.is_Atom:
+        return 0
+    c = sum(_weighted_ops(a) for a in e.args)
+    if e.is_Mul:
+        return c + len(e.args) - 1 - (1 if e.args[0] == -1 else 0)                  # (a sign is an operand modifier)
+    if e.is_Add:                                                   # a product term's last multiply fuses with an add (v_fma_f64)
+        return c + len(e.args) - 1 - min(sum(1 for a in e.args if a.is_Mul and not (len(a.args) == 2 and a.args[0] == -1)), len(e.args) - 1)
+    if e.is_Pow:
+        ex = e.exp
+        if ex.is_Integer:
+            return c + (abs(int(ex)) - 1) + (8 if ex < 0 else 0)
+        if ex in (sympy.Rational(1, 2), sympy.Rational(-1, 2)):
+            return c + (8 if ex > 0 else 16)
+        return c + 40
+    if isinstance(e, (sympy.Abs, sympy.Max, sympy.Min)):
+        return c + len(e.args) - 1
+    if isinstance(e, (_Rcp, _Sqrt)):
+        return c + 8
+    return c + 20
 
 
 def _arity(fn):
@@ -47,7 +116,7 @@ def _arity(fn):
 
 
 class SympyPDE:
-    def __init__(self, n_vars, flux, max_eigenvalue, max_dim=3, name="user", source=None, ncp=None):
+    def __init__(self, n_vars, flux, max_eigenvalue, max_dim=3, name="user", source=None, ncp=None, max_aux=None):
         """flux(q, d) -> n_vars expressions, max_eigenvalue(q, d) -> one, in the state symbols q; d = 0-based normal.
         source(q) -> n_vars expressions (optional): the algebraic source S(q) of q_t + div F(q) = S(q) -- the hook the
         reference's harness declares beside flux and maxEigenvalue (`Unit test/correctness_test.cpp:16-23`).  It enters the
@@ -68,6 +137,8 @@ class SympyPDE:
         if not 1 <= n_vars <= 8:
             raise ValueError("n_vars must be 1..8")
         self.n_vars, self.max_dim, self.name = n_vars, max_dim, name
+        self.max_aux = max_aux                      # cached flux scalars per node: None = as many as pay and fit (see _analyse)
+        self._aux = None
         self.q = self.state(n_vars)
         self.x = list(sympy.symbols("x0:3", real=True))
         self.t = sympy.Symbol("t", real=True)
@@ -107,15 +178,148 @@ class SympyPDE:
         return list(sympy.symbols("q0:%d" % n_vars, real=True))
 
     # -- code generation -------------------------------------------------------------------------
-    def _block(self, exprs, targets, indent):
-        pr = _DevicePrinter()
+    def _block(self, exprs, targets, indent, fast=False, extra=None):
+        pr = _DevicePrinter(fast)
         subs = {s: sympy.Symbol("q[%d]" % i) for i, s in enumerate(self.q)}
         subs.update({s: sympy.Symbol("x[%d]" % i) for i, s in enumerate(self.x)})
         subs.update({s: sympy.Symbol("dq[%d]" % i) for i, s in enumerate(self.dq)})
-        repl, red = sympy.cse([e.subs(subs) for e in exprs], symbols=sympy.numbered_symbols("t_"))
+        subs.update(extra or {})
+        exprs = [sympy.sympify(e).xreplace(subs) for e in exprs]
+        if fast:
+            exprs = [_fast_forms(e) for e in exprs]
+        repl, red = sympy.cse(exprs, symbols=sympy.numbered_symbols("t_"))
         lines = ["%sconst double %s = %s;" % (indent, pr.doprint(a), pr.doprint(b)) for a, b in repl]
         lines += ["%s%s = %s;" % (indent, t, pr.doprint(e)) for t, e in zip(targets, red)]
         return "\n".join(lines)
+
+    @staticmethod
+    def _block_ops(exprs):
+        repl, red = sympy.cse(list(exprs))
+        return sum(_weighted_ops(b) for _, b in repl) + sum(_weighted_ops(e) for e in red)
+
+    def _best_form(self, exprs, gens):
+        """The cheapest (weighted instruction count after common-subexpression elimination) of a few algebraic forms of a block of
+        expressions: as written, expanded, with common terms factored, and collected in the cached scalars / scale symbols `gens` with
+        factored coefficients (that one finds `a0 (n0 q1 + n1 q2 + n2 q3) q1 + n0 a1` in the direction-masked Euler flux)."""
+        exprs = [sympy.sympify(e) for e in exprs]
+        alts = []
+        for e in exprs:
+            a = [e]
+            for f in (sympy.expand, sympy.factor_terms,
+                      lambda x: sympy.collect(sympy.expand(x), gens, func=sympy.factor) if gens else sympy.factor(x)):
+                try:
+                    g = f(e)
+                    if g not in a:
+                        a.append(g)
+                except Exception:                                  # (a form SymPy cannot build for this expression is simply not a candidate)
+                    pass
+            alts.append(a)
+        # whole block in one form, then expression by expression while the count falls (the forms interact through shared sub-expressions)
+        nforms = max(len(a) for a in alts)
+        best = min(([a[min(k, len(a) - 1)] for a in alts] for k in range(nforms)), key=self._block_ops)
+        score = self._block_ops(best)
+        for _ in range(2):
+            for i, a in enumerate(alts):
+                for g in a:
+                    trial = best[:i] + [g] + best[i + 1:]
+                    sc_ = self._block_ops(trial)
+                    if sc_ < score:
+                        best, score = trial, sc_
+        return best
+
+    def _cap_aux(self):
+        """Cached scalars the tuned kernels have LDS for: exa_dg_reg.hpp (N = 6: two cells of (4 NV + NAUX) slots of 2 x 217 doubles + 2 KB in
+        160 KB) and exa_dg_m8.hpp (N = 8: (3 NV + NAUX) slots of 2 x 560 doubles + 6 KB); a kernel that does not fit NV at all does not count."""
+        caps = [c for c in ((163840 - 2048) // (2 * 8 * 434) - 4 * self.n_vars, (163840 - 6144) // (8 * 1120) - 3 * self.n_vars) if c >= 0]
+        return min(caps + [4])
+
+    def _analyse(self):
+        """Pick the per-node scalars worth caching (struct member `aux`): sub-expressions of the fluxes that at least two directions share and
+        that cost more to recompute than an LDS load (greedy by saved instructions, bounded by the kernels' LDS).  For Euler written the
+        obvious way this finds 1/rho and p -- what the hand-written exa::Euler caches."""
+        if getattr(self, "_aux", None) is not None:
+            return
+        n = self.n_vars
+        flat = [e for d in range(self.max_dim) for e in self.flux_exprs[d]]
+        repl, red = sympy.cse(flat, symbols=sympy.numbered_symbols("c_"))
+        defs = dict(repl)
+        order = {t: i for i, (t, _) in enumerate(repl)}
+
+        def deps(e):
+            return [s for s in e.free_symbols if s in defs]
+        uses = {t: set() for t in defs}
+        for i, r in enumerate(red):
+            stack, seen = deps(r), set()
+            while stack:
+                t = stack.pop()
+                if t in seen:
+                    continue
+                seen.add(t)
+                uses[t].add(i // n)
+                stack += deps(defs[t])
+
+        def full(e):
+            while True:
+                fs = {s: defs[s] for s in e.free_symbols if s in defs}
+                if not fs:
+                    return e
+                e = e.xreplace(fs)
+        # shared temporaries that differ by a cheap term are chained (SymPy distributes a numeric factor over a sum, so `E + p` with
+        # p = 0.4 (E - ...) arrives as `1.4 E - ...`, unrelated to p as far as the sub-expression pass can see): t_j := t_i + (t_j - t_i)
+        shared = [t for t, _ in repl if len(uses[t]) >= 2]
+        for jx, tj in enumerate(shared):
+            for ti in shared[:jx]:
+                if ti in defs[tj].free_symbols or _weighted_ops(defs[ti]) < 1:
+                    continue
+                diff = sympy.expand(full(defs[tj]) - full(defs[ti]))
+                # (1.4 - 0.4 is 0.9999999999999999 in binary: coefficients within rounding of an integer are that integer)
+                diff = diff.xreplace({f: sympy.Integer(round(f)) for f in diff.atoms(sympy.Float) if abs(f - round(f)) < 1e-14})
+                if _weighted_ops(diff) <= 1 and not (diff.free_symbols & set(defs)):
+                    defs[tj] = ti + diff
+                    break
+
+        def reach(exprs, stop, own=()):
+            """weighted instructions of `exprs` plus every temporary they need (each once), not descending into `stop` (`own`: temporaries
+            whose definitions are among `exprs`)"""
+            seen, total, stack = set(own), 0, list(exprs)
+            while stack:
+                e = stack.pop()
+                total += _weighted_ops(e)
+                for s in deps(e):
+                    if s not in stop and s not in seen:
+                        seen.add(s)
+                        stack.append(defs[s])
+            return total
+
+        def objective(chosen):
+            """per node and level: the flux of every direction (each recomputes what is not cached) + the owner's aux block + the LDS
+            round trip of the cached scalars (one store, one load per direction)"""
+            per_dir = sum(reach(red[d * n:(d + 1) * n], chosen) for d in range(self.max_dim))
+            return per_dir + reach([defs[t] for t in chosen], (), chosen) + (self.max_dim + 1) * len(chosen)
+        chosen = []
+        cap = self._cap_aux() if self.max_aux is None else self.max_aux
+        while len(chosen) < cap:
+            now = objective(chosen)
+            best = min(((objective(chosen + [t]), order[t], t) for t in defs if t not in chosen and len(uses[t]) >= 2), default=None)
+            if best is None or best[0] >= now:
+                break
+            chosen.append(best[2])
+        chosen.sort(key=lambda t: order[t])
+        self._aux_syms = [sympy.Symbol("a[%d]" % k) for k in range(len(chosen))]
+        to_a = dict(zip(chosen, self._aux_syms))
+
+        def inline(e, keep):
+            while True:
+                fs = {s: defs[s] for s in e.free_symbols if s in defs and s not in keep}
+                if not fs:
+                    return e
+                e = e.xreplace(fs)
+        self._aux = [inline(defs[t], ()) for t in chosen]                                    # in the state alone
+        self._flux_a = [[inline(red[d * n + v], chosen).xreplace(to_a) for v in range(n)] for d in range(self.max_dim)]   # in the state + cached scalars
+
+    def n_aux(self):
+        self._analyse()
+        return len(self._aux)
 
     def source(self):
         n = self.n_vars
@@ -141,17 +345,65 @@ class SympyPDE:
                            "        default:\n            for (int v = 0; v < NV; v++) out[v] = 0.0;\n        }\n    }\n" % (sig, "\n".join(cases)))
         if self.uses_xt:
             return self._source_xt(flux_cases, eig_cases, src_member)
+        return self._source_tuned(flux_cases, eig_cases, src_member)
+
+    def _source_tuned(self, flux_cases, eig_cases, src_member):
+        """Term set of the state alone (no position / time, no ncp): the interface the tuned ADER-DG kernels are written against, with what
+        the hand-written exa::Euler has -- per-node cached scalars shared by the directions (aux / aux_fast), reciprocals and square roots by
+        the fast sequences in the members only the ADER-DG kernels call, the scale folded into the flux (flux_scaled), and the flux for a
+        per-LANE normal as straight-line code over per-lane masks (Dir / dir_init / flux_scaled_dir; exa_dg_reg.hpp) where that form costs
+        less than the divergent switch it replaces."""
+        self._analyse()
+        n, na, md = self.n_vars, len(self._aux), self.max_dim
+        sc = sympy.Symbol("sc")
+        A = self._aux_syms
+        ind = "            "
+        Fv = ["F[%d]" % v for v in range(n)]
+        aux_t = ["a[%d]" % k for k in range(na)]
+        aux_ieee = self._block(self._aux, aux_t, "        ") if na else ""
+        aux_fast = self._block(self._aux, aux_t, "        ", fast=True) if na else ""
+        flux_d, flux_sc = [], []
+        for d in range(md):
+            flux_d.append("        if constexpr (D == %d) {\n%s\n        }" % (d, self._block(self._best_form(self._flux_a[d], A), Fv, ind, fast=True)))
+            scaled = self._best_form([sc * e for e in self._flux_a[d]], A + [sc])
+            flux_sc.append("        if constexpr (D == %d) {\n%s\n        }" % (d, self._block(scaled, Fv, ind, fast=True)))
+        dir_member = ""
+        self.dir_form = None
+        if md == 3:
+            nn = list(sympy.symbols("n0:3"))
+            masked = self._best_form([sum(nn[d] * self._flux_a[d][v] for d in range(3)) for v in range(n)], A + nn)
+            ops_m = self._block_ops(masked)
+            ops_d = max(self._block_ops([sc * e for e in self._flux_a[d]]) for d in range(3))
+            self.dir_form = {"masked_ops": ops_m, "one_direction_ops": ops_d}
+            # two of the four derive waves of exa_dg_reg.hpp hold pencils of two directions: the switch costs them 2 x the flux
+            if ops_m <= 1.8 * ops_d:
+                body = self._block(masked, Fv, "        ", fast=True, extra={nn[d]: sympy.Symbol("c.n[%d]" % d) for d in range(3)})
+                dir_member = ("    // normal chosen per LANE: n[k] = scale for the lane's own direction, 0 for the others (weighted %d instructions against %d for one\n"
+                              "    // compile-time direction)\n"
+                              "    struct Dir { double n[3]; };\n"
+                              "    __device__ static inline void dir_init(Dir& c, int d, double sc) {\n"
+                              "        c.n[0] = d == 0 ? sc : 0.0;\n        c.n[1] = d == 1 ? sc : 0.0;\n        c.n[2] = d == 2 ? sc : 0.0;\n    }\n"
+                              "    __device__ static inline void flux_scaled_dir(const double* q, const double* a, const Dir& c, double* F) {\n%s\n    }\n"
+                              % (ops_m, ops_d, body))
+        eig_fast = []
+        for d in range(md):
+            eig_fast.append("        case %d: {\n%s\n            return lam;\n        }" % (d, self._block([self.eig_exprs[d]], ["const double lam"], ind, fast=True)))
         return """// generated by exahype_amd/pde_codegen.py from SymPy expressions -- user PDE term set "%s"
 #pragma once
 #include <hip/hip_runtime.h>
+#include "exa_pde.hpp"
 namespace exa {
 struct UserPDE {
     static constexpr int NV = %d;
     static constexpr int NFLUX = %d;
-    static constexpr int NAUX = 1;
+    static constexpr int NAUX = %d;             // per-node scalars shared by the directions, found in the expressions (pde_codegen._analyse)
     static constexpr int MAXDIM = %d;
-    __device__ static inline void aux(const double*, double* a) { a[0] = 0.0; }
-    __device__ static inline void aux_fast(const double*, double* a) { a[0] = 0.0; }
+    __device__ static inline void aux(const double* q, double* a) {
+%s
+    }
+    __device__ static inline void aux_fast(const double* q, double* a) {
+%s
+    }
     __device__ static inline void flux_rt(const double* q, int d, double* F) {
         switch (d) {
 %s
@@ -159,22 +411,34 @@ struct UserPDE {
             for (int v = 0; v < NV; v++) F[v] = 0.0;
         }
     }
-    template <int D> __device__ static inline void flux(const double* q, const double*, double* F) { flux_rt(q, D, F); }
-    template <int D> __device__ static inline void flux_scaled(const double* q, const double*, double sc, double* F) {
-        flux_rt(q, D, F);
-#pragma unroll
-        for (int v = 0; v < NV; v++) F[v] *= sc;
+    template <int D> __device__ static inline void flux(const double* q, const double* a, double* F) {
+%s
+        if constexpr (D >= MAXDIM) {
+            for (int v = 0; v < NV; v++) F[v] = 0.0;
+        }
     }
-    __device__ static inline double maxeig(const double* q, int d) {
+    template <int D> __device__ static inline void flux_scaled(const double* q, const double* a, double sc, double* F) {
+%s
+        if constexpr (D >= MAXDIM) {
+            for (int v = 0; v < NV; v++) F[v] = 0.0;
+        }
+    }
+%s    __device__ static inline double maxeig(const double* q, int d) {
         switch (d) {
 %s
         }
         return 0.0;
     }
-    __device__ static inline double maxeig_fast(const double* q, int d) { return maxeig(q, d); }
+    __device__ static inline double maxeig_fast(const double* q, int d) {
+        switch (d) {
+%s
+        }
+        return 0.0;
+    }
 %s};
 }  // namespace exa
-""" % (self.name, n, n, self.max_dim, "\n".join(flux_cases), "\n".join(eig_cases), src_member)
+""" % (self.name, n, n, na, md, aux_ieee, aux_fast, "\n".join(flux_cases), "\n".join(flux_d), "\n".join(flux_sc), dir_member,
+       "\n".join(eig_cases), "\n".join(eig_fast), src_member)
 
     def _source_xt(self, flux_cases, eig_cases, src_member):
         """Term set whose expressions contain the volume centre x or the time t: the *_xt members carry them (fv_rusanov.hip uses them

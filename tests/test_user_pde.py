@@ -147,14 +147,21 @@ def test_user_pde_fv_rusanov_vs_numpy():
 
 
 @pytest.mark.gpu
-def test_euler_from_sympy_equals_builtin_euler():
+@pytest.mark.parametrize("N", [3, 6, 8])
+def test_euler_from_sympy_equals_builtin_euler(N):
+    """The north-star's drop-in sentence on the kernels that carry the benchmarks: N = 6 is the register-resident stage A (generated
+    Dir / flux_scaled_dir), N = 8 the matrix-pipe one (generated flux_scaled + cached scalars), N = 3 the generic LDS kernel."""
     from exahype_amd import solvers as exa
     from tests.util import euler_dg_state
     p = euler_sympy()
-    N, nc = 3, (2, 2, 2)
+    nc = (2, 2, 2) if N < 8 else (2, 1, 2)
     u = euler_dg_state(nc + (N,) * 3, seed=21)
     a = exa.AderDgSolver(3, N, nc, pde=exa.PDE_EULER)
     b = exa.AderDgSolver(3, N, nc, pde=p.register())
+    if N == 6:
+        assert "reg_kernel" in a.stage_a_kernel_name() and "reg_kernel" in b.stage_a_kernel_name() and "UserPDE" in b.stage_a_kernel_name()
+    if N == 8:
+        assert "m8_kernel" in a.stage_a_kernel_name() and "m8_kernel" in b.stage_a_kernel_name()
     a.upload(u); b.upload(u)
     for _ in range(2):
         a.step(1e-3); b.step(1e-3)
@@ -164,6 +171,56 @@ def test_euler_from_sympy_equals_builtin_euler():
         Fa, la = exa.pde_eval(exa.PDE_EULER, d, Q)
         Fb, lb = exa.pde_eval(p.register(), d, Q)
         assert np.max(np.abs(Fa - Fb)) < 1e-13 and np.max(np.abs(la - lb)) < 1e-13
+
+
+def test_generated_term_set_caches_shared_scalars_and_masks_the_direction():
+    """pde_codegen._analyse: Euler written the obvious way gets the two cached scalars of the hand-written exa::Euler (1/rho, p), fast
+    reciprocals in the members the ADER-DG kernels call (IEEE in flux_rt / maxeig: the FV path), and the per-lane-normal flux as
+    straight-line code; a system with nothing to share gets no LDS slot."""
+    p = euler_sympy()
+    src = p.source()
+    assert p.n_aux() == 2 and "NAUX = 2" in src
+    aux = [sympy.simplify(e) for e in p._aux]
+    q = p.q
+    assert sympy.simplify(aux[0] - 1 / q[0]) == 0
+    assert sympy.simplify(aux[1] - sympy.Float(0.4) * (q[4] - (q[1] ** 2 + q[2] ** 2 + q[3] ** 2) / (2 * q[0]))) == 0
+    assert "struct Dir" in src and "flux_scaled_dir" in src and p.dir_form["masked_ops"] <= 1.8 * p.dir_form["one_direction_ops"]
+    body = lambda name: src[src.index(name):src.index("}", src.index(name))]
+    assert "exa::fast_rcp" in body("void aux_fast(") and "1.0/" in body("void aux(")
+    tuned = src[src.index("template <int D> __device__ static inline void flux("):src.index("__device__ static inline double maxeig(")]
+    assert "/" not in tuned.replace("//", "")                         # no IEEE division where the ADER-DG kernels evaluate the flux
+    assert "exa::fast_sqrt" in src[src.index("maxeig_fast("):] and "sqrt(" in body("double maxeig(")
+    # the benchmark's own statement of the system (bench.sympy_euler: u_n (E + p), quotients instead of a named 1/rho) ends at the same two scalars
+    import bench
+    b = bench.sympy_euler()
+    assert b.n_aux() == 2 and sympy.simplify(b._aux[0] - aux[0]) == 0 and sympy.simplify(b._aux[1] - aux[1]) == 0 and "struct Dir" in b.source()
+    r = reaction_advection()
+    assert r.n_aux() == 0 and "NAUX = 0" in r.source()
+    w = swe()
+    assert w.n_aux() == 1 and sympy.simplify(w._aux[0] - 1 / w.q[0]) == 0 and "struct Dir" not in w.source()     # (2-D only: no per-lane normal)
+    assert euler_sympy().__class__(5, lambda q, d: euler_sympy().flux_exprs[d], lambda q, d: euler_sympy().eig_exprs[d], max_aux=0).n_aux() == 0
+
+
+def test_generated_flux_forms_agree_with_the_expressions():
+    """Every generated form of the flux (cached scalars, scaled, direction-masked) is the user's expression: evaluated symbolically at
+    random states."""
+    p = euler_sympy()
+    p._analyse()
+    rng = np.random.default_rng(5)
+    A = p._aux_syms
+    for _ in range(3):
+        qv = {s: float(v) for s, v in zip(p.q, [1.0 + rng.random(), rng.random() - 0.5, rng.random() - 0.5, rng.random() - 0.5, 3.0 + rng.random()])}
+        av = {a: e.xreplace(qv) for a, e in zip(A, p._aux)}
+        for d in range(3):
+            for v in range(5):
+                want = float(p.flux_exprs[d][v].xreplace(qv))
+                assert abs(float(p._flux_a[d][v].xreplace(av).xreplace(qv)) - want) < 1e-13
+        nn = list(sympy.symbols("n0:3"))
+        masked = p._best_form([sum(nn[d] * p._flux_a[d][v] for d in range(3)) for v in range(5)], A + nn)
+        for d in range(3):
+            nv = {nn[k]: (0.7 if k == d else 0.0) for k in range(3)}
+            for v in range(5):
+                assert abs(float(masked[v].xreplace(nv).xreplace(av).xreplace(qv)) - 0.7 * float(p.flux_exprs[d][v].xreplace(qv))) < 1e-13
 
 
 def _swe_kernel(n_patches, patch_size=4, halo_size=0):
