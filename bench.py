@@ -272,6 +272,31 @@ def run_cfg2(a, torch, exa, world, rank, local, pde=None):
     for _ in range(a.warmup):
         s.step(dt)
     sync()
+    reserve_trial = None
+    if sharded and not a.no_reserve_trial:
+        # CUs for RCCL's transport kernels: the interior stage A is a persistent grid that fills every CU, and a resident workgroup is not
+        # preempted by a higher-priority stream.  Two untimed steps each with the grid 0 and 8 workgroups short of the chip; the faster
+        # setting (max over ranks) is kept for the timed steps, both are reported.
+        reserve_trial = {}
+        for k in (0, 8):
+            s.set_reserve_cus(k)
+            s.step(dt)                                               # (settle)
+            s.exchange_events = []
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                s.step(dt)
+            sync()
+            el_k = (time.perf_counter() - t0) / 2
+            xp_k = max(max(0.0, ev[0].elapsed_time(ev[2]) - ev[0].elapsed_time(ev[4])) for ev in s.exchange_events)
+            tk = torch.tensor([el_k, xp_k], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+            reserve_trial[k] = {"ms_per_step": 1e3 * float(tk[0]), "exposed_exchange_ms": float(tk[1])}
+        chosen = min(reserve_trial, key=lambda k: reserve_trial[k]["ms_per_step"])
+        s.set_reserve_cus(chosen)
+        s.step(dt)
+        sync()
     s.stage_a_events = []                  # stage-A launch durations: events on the stream the kernels are launched on
     if sharded:
         s.exchange_events = []
@@ -327,14 +352,15 @@ def run_cfg2(a, torch, exa, world, rank, local, pde=None):
             out["cpu_reference_fv"] = cpu_reference_fv()
     if sharded:
         # the exchange (pack + RCCL send/recv) on the comm stream against the interior stage A on the compute stream
-        ex, ov, xp = [], [], []
-        for ready, c0, c1, i0, i1 in s.exchange_events:
-            cs, ce = ready.elapsed_time(c0), ready.elapsed_time(c1)
+        ex, ov, xp, pk = [], [], [], []
+        for ready, c0, c1, i0, i1, p1 in s.exchange_events:
+            cs, ce, ps = ready.elapsed_time(c0), ready.elapsed_time(c1), ready.elapsed_time(p1)
             is_, ie = ready.elapsed_time(i0), ready.elapsed_time(i1)
-            ex.append(ce - cs)
+            ex.append(ce - ps)                         # the RCCL send / recv group alone (start() .. finish())
+            pk.append(ps - cs)                         # the pack copies in front of it
             ov.append(max(0.0, min(ce, ie) - max(cs, is_)) / max(ce - cs, 1e-9))
             xp.append(max(0.0, ce - ie))               # what the exchange adds to the step: its end past the end of the interior stage A
-        mine = torch.tensor([sum(ex) / len(ex), sum(ov) / len(ov), ta * 1e3, sum(xp) / len(xp)], dtype=torch.float64,
+        mine = torch.tensor([sum(ex) / len(ex), sum(ov) / len(ov), ta * 1e3, sum(xp) / len(xp), sum(pk) / len(pk)], dtype=torch.float64,
                             device="cuda" if a.backend == "nccl" else "cpu")
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
@@ -345,7 +371,12 @@ def run_cfg2(a, torch, exa, world, rank, local, pde=None):
         out["rccl_ranks"] = dist.get_world_size()
         out["backend"] = dist.get_backend()
         out["devices"] = names
-        out["exchange_ms"] = max(float(v[0]) for v in allv)
+        out["exchange_ms"] = max(float(v[0]) for v in allv)              # RCCL span only; the pack copies are `pack_ms`
+        out["pack_ms"] = max(float(v[4]) for v in allv)
+        out["high_priority_comm"] = {"comm_stream": True, "nccl_process_group_stream": bool(a.backend == "nccl")}
+        if reserve_trial is not None:
+            out["reserve_cus_chosen"] = s.reserve_cus
+            out["reserve_cus_trial"] = {str(k): v for k, v in reserve_trial.items()}
         out["overlap_frac"] = min(float(v[1]) for v in allv)
         out["stage_a_ms"] = max(float(v[2]) for v in allv)
         out["exposed_exchange_ms"] = max(float(v[3]) for v in allv)
@@ -487,6 +518,11 @@ def run_fv_ref(a, torch, exa, local):
     return out
 
 
+def nccl_options():
+    import torch.distributed as dist
+    return dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -498,6 +534,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="cfg2 on one GPU: do not append the short cfg1 / cfg4 / fv-ref runs (`other_configs`) to the line")
+    ap.add_argument("--no-reserve-trial", action="store_true", help="sharded runs: skip the warm-up trial of reserve_cus 0 / 8")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path with host-staged exchange")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--self-exchange", action="store_true",
@@ -534,7 +571,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # RCCL's transport kernels run on the process group's OWN stream (not on the solver's comm stream, which only orders them): ask
+            # for a high-priority one, so that they are dispatched ahead of the interior launch's remaining workgroups
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=nccl_options())
         else:
             dist.init_process_group(a.backend)
     elif a.self_exchange:
@@ -543,7 +582,7 @@ def main():
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
         dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port,
-                                device_id=torch.device("cuda", local))
+                                device_id=torch.device("cuda", local), pg_options=nccl_options())
 
     if a.config == "cfg2":
         out = run_cfg2(a, torch, exa, world, rank, local)

@@ -31,7 +31,10 @@ template <int DIM, int N, class PDE> struct StagePlain {
     static constexpr int NN = ipow(N, DIM), NF = ipow(N, DIM - 1);
     static constexpr int NT = 256;
     static constexpr int IMG = N * NN * NV;                           // one space-time image
-    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(2 * IMG + NN * NV);
+    // second region: the right-hand side (N levels) during the Picard loop, then qbar | Fbar_a = 1 + DIM node arrays -- more than N of them
+    // at N < DIM + 1 (3-D N = 2, 3; 2-D N = 2), so the region is sized for the larger of the two and u sits behind it
+    static constexpr int BIMG = (N > 1 + DIM ? N : 1 + DIM) * NN * NV;
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(IMG + BIMG + NN * NV);
     static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NN <= NT;
 };
 
@@ -44,7 +47,7 @@ dg_stage_a_plain_kernel(const double* u_in, double* u_out, double* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) double plain_lds[];
     double* A = plain_lds;              // iterate      [level][node][var]
     double* B = plain_lds + IMG;        // right-hand side, later qbar | Fbar_a  ([array][node][var])
-    double* U = plain_lds + 2 * IMG;    // u            [node][var]
+    double* U = plain_lds + IMG + SP::BIMG;    // u     [node][var]
     const int tid = threadIdx.x;
     const long cell = box.cell(blockIdx.x);
     if (cell < 0) return;

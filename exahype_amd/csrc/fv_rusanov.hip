@@ -825,7 +825,19 @@ static int fv_dispatch(int P, int H, int m, int V, long n_patches, double* Q, do
 template <int DIM, class PDE>
 static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double* Q, double dt, double h, const long* slot, hipStream_t s,
                    const FvCellData& cd) {
-    if (mode == 0) return fv_dispatch<DIM, PDE, 0>(P, H, m, V, n_patches, Q, dt, h, slot, s, cd);
+    if (mode == 0) {
+        // the faithful mode IS the reference's statement list (test.cpp:60-95): it has no source and no non-conservative product -- a term
+        // set that carries one would be integrated as a different PDE without a word
+        if constexpr (pde_has_ncp<PDE>::value || pde_has_source<PDE>::value) {
+            set_error("FV faithful mode (the reference's statement list) has no source / ncp term: use EXA_FV_RUSANOV for this term set");
+            return -1;
+        } else {
+            return fv_dispatch<DIM, PDE, 0>(P, H, m, V, n_patches, Q, dt, h, slot, s, cd);
+        }
+    }
+    if constexpr (pde_has_xt<PDE>::value) {
+        if (slot) { set_error("FV Rusanov: the masked patch update carries no patch centres / time; term sets whose terms depend on position / time are not served"); return -1; }
+    }
     return fv_dispatch<DIM, PDE, 1>(P, H, m, V, n_patches, Q, dt, h, slot, s, cd);
 }
 

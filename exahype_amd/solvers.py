@@ -67,6 +67,8 @@ class FVRusanovKernel:
         if slot is not None:
             if not (slot.is_cuda and slot.dtype == torch.int64 and slot.is_contiguous() and slot.numel() >= self.shape[0]):
                 raise ValueError("slot must be a contiguous int64 CUDA tensor with one entry per patch")
+            if centres is not None or t != 0.0:
+                raise ValueError("the masked patch update (slot=) carries no patch centres / time")
             check(self.lib.exa_fv_time_step_device_masked(self._plan, C.c_void_p(Q.data_ptr()), C.c_void_p(slot.data_ptr()),
                                                           dt, h, _stream_ptr()))
             return Q
@@ -97,17 +99,25 @@ class FVRusanovKernel:
         n_out = self.lib.exa_fv_qout_count(self._plan)
         dim = len(self.shape) - 2
         P = round((n_out // (self.shape[0] * self.shape[-1])) ** (1.0 / dim))
+        if host and out is not None and not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.size == n_out):
+            raise ValueError("out (numpy input): a C-contiguous float64 array of %d entries" % n_out)
         qo = torch.empty((self.shape[0],) + (P,) * dim + (self.shape[-1],), dtype=torch.float64, device=dev) if out is None or host else out
-        if qo.numel() != n_out or not qo.is_contiguous():
-            raise ValueError("out must hold %d contiguous float64 entries" % n_out)
+        if not (isinstance(qo, torch.Tensor) and qo.is_cuda and qo.device == dev and qo.dtype == torch.float64 and qo.is_contiguous() and qo.numel() == n_out):
+            raise ValueError("out must be a contiguous float64 CUDA tensor of %d entries on %s" % (n_out, dev))
         cen = None
         if centres is not None:
             cen = torch.as_tensor(np.ascontiguousarray(centres), dtype=torch.float64).to(dev) if not isinstance(centres, torch.Tensor) else centres
-            if cen.numel() != self.shape[0] * dim or not cen.is_contiguous():
-                raise ValueError("centres must be [n_patches][dim]")
+            if not (cen.is_cuda and cen.device == dev and cen.dtype == torch.float64 and cen.is_contiguous() and cen.numel() == self.shape[0] * dim):
+                raise ValueError("centres must be a contiguous float64 CUDA tensor [n_patches][dim] on %s (or an array)" % dev)
         check(self.lib.exa_fv_time_step_device_oop(self._plan, C.c_void_p(qi.data_ptr()), C.c_void_p(qo.data_ptr()),
                                                    C.c_void_p(cen.data_ptr()) if cen is not None else None, t, dt, h, _stream_ptr()))
-        return qo.cpu().numpy() if host else qo
+        if host:
+            res = qo.cpu().numpy()
+            if out is not None:
+                out.reshape(res.shape)[...] = res
+                return out
+            return res
+        return qo
 
     def __del__(self):
         try:
@@ -352,7 +362,7 @@ class AderDgSolver:
         self._fused = bool(fused_single_stage) and bool(self.lib.exa_dg_has_fused_step(h))
         self._u2 = None
         # measurement hooks (bench.py): stage_a_events collects one (start, end) event pair per stage-A launch on the
-        # launching stream; exchange_events one (shell done, comm start, comm end, interior start, interior end) tuple
+        # launching stream; exchange_events one (shell done, comm start, comm end, interior start, interior end, pack end) tuple
         # per sharded step.  None = off: the product path records nothing.
         self.stage_a_events = None
         self.exchange_events = None
@@ -364,9 +374,14 @@ class AderDgSolver:
             # the persistent grids that many workgroups below the resident count; it costs 0.4 % of stage A per CU and bought nothing
             # in the rehearsal, so the default is 0 (EXA_RESERVE_CUS / the argument are there for a node where RCCL needs resident CUs).
             self.comm_stream = torch.cuda.Stream(device=self.dev, priority=-1)
-            self.reserve_cus = int(os.environ.get("EXA_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
-            check(self.lib.exa_dg_plan_set_stage_a_reserve(h, self.reserve_cus))
+            self.set_reserve_cus(int(os.environ.get("EXA_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus))
             self.shell, self.interior = part.shell_and_interior(self.nc)
+
+    def set_reserve_cus(self, workgroups):
+        """Keep the persistent stage-A grids `workgroups` below the resident count (CUs left to RCCL's transport kernels while the interior
+        launch runs); bench.py tries 0 and 8 in its warm-up on a real multi-GPU node and keeps the faster."""
+        self.reserve_cus = int(workgroups)
+        check(self.lib.exa_dg_plan_set_stage_a_reserve(self._plan, self.reserve_cus))
 
     # -- data movement ---------------------------------------------------------------------
     @property
@@ -534,12 +549,14 @@ class AderDgSolver:
             self.trace, self._trace2 = self._trace2, self.trace      # (the pack below reads the NEW traces; the interior kernel gets them swapped back)
         ready = torch.cuda.Event(enable_timing=timed)
         ready.record(cur)
-        c0, c1, i0, i1 = mk(), mk(), mk(), mk()
+        c0, p1, c1, i0, i1 = mk(), mk(), mk(), mk(), mk()
         with torch.cuda.stream(self.comm_stream):      # ... its traces travel on the comm stream ...
             self.comm_stream.wait_event(ready)
             if timed:
                 c0.record()
             self._pack_faces()
+            if timed:
+                p1.record()                            # pack copies: c0 .. p1; the RCCL send / recv group: p1 .. c1
             self.halo.start()
         lo, hi = self.interior                         # ... while the interior cells run stage A
         if timed:
@@ -562,7 +579,7 @@ class AderDgSolver:
         else:
             self.riemann_corrector(dt)
         if timed:
-            self.exchange_events.append((ready, c0, c1, i0, i1))
+            self.exchange_events.append((ready, c0, c1, i0, i1, p1))
 
     def __del__(self):
         try:
@@ -859,6 +876,7 @@ class SubcellLimiter:
         `capacity` cannot be served: `self.overflow` (0-dim CUDA bool) says so -- see check()."""
         torch = _torch()
         s = self.s
+        self.check()                                           # a COMPLETED earlier step past the capacity raises here (no synchronisation)
         if isinstance(mask, torch.Tensor):
             m = mask.to(device=s.dev, dtype=torch.bool)
         else:
@@ -888,6 +906,12 @@ class SubcellLimiter:
                                                C.c_void_p(s.u.data_ptr()), _stream_ptr()))
         return count
 
+    def download(self):
+        """The solver's u on the host -- after a WAITING check(): a result in which some troubled cells kept the unlimited DG solution is
+        not handed out silently."""
+        self.check(wait=True)
+        return self.s.download()
+
     def _post_overflow(self):
         """Copy the overflow flag to pinned host memory behind an event; check() reads it once the event has passed."""
         torch = _torch()
@@ -901,6 +925,7 @@ class SubcellLimiter:
         if wait:
             self._ovf_event.synchronize()
         if self._ovf_event.query() and bool(self._ovf_host[0]):
+            self._ovf_event.synchronize()                                                   # (the latest copy into the pinned byte has landed)
             self.overflow = _torch().zeros((), dtype=_torch().bool, device=self.s.dev)      # reported: start over
             self._ovf_host[0] = 0
             raise RuntimeError("SubcellLimiter: a step since the last check() had more troubled cells than capacity = %d "

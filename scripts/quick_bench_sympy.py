@@ -4,14 +4,16 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from exahype_amd import solvers as exa
-from tests.test_user_pde import euler_sympy
+from bench import sympy_euler as euler_sympy
 
 N, nc = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 spde = euler_sympy()
 pid = spde.register()
 res = {}
-for name, pde in (("built-in", exa.PDE_EULER), ("sympy", pid)):
+order = (("built-in", exa.PDE_EULER), ("sympy", pid))
+if os.environ.get("EXA_SYMPY_FIRST"): order = order[::-1]
+for name, pde in order:
     if name == "built-in" and os.environ.get("EXA_SYMPY_ONLY"):
         continue
     s = exa.AderDgSolver(3, N, (nc,) * 3, pde=pde, n_vars=5)

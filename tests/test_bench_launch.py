@@ -48,8 +48,11 @@ def test_self_launched_ranks_share_one_gpu_over_gloo(gpus):
     out = json.loads(lines[0])
     assert out["n_gpus"] == gpus and out["rccl_ranks"] == gpus and out["backend"] == "gloo" and len(out["devices"]) == gpus
     assert out["finite"] and out["value"] > 0 and out["scaling"] == "weak"
-    assert out["exchange_ms"] > 0 and 0.0 <= out["overlap_frac"] <= 1.0
+    assert out["exchange_ms"] > 0 and 0.0 <= out["overlap_frac"] <= 1.0 and out["pack_ms"] >= 0
     assert out["config"]["parallelism"] == {2: "cartesian-2x1x1", 4: "cartesian-2x2x1"}[gpus]
+    # the warm-up tried the persistent grids 0 and 8 workgroups short of the chip and kept the faster setting
+    assert out["reserve_cus_chosen"] in (0, 8) and set(out["reserve_cus_trial"]) == {"0", "8"}
+    assert all(v["ms_per_step"] > 0 and v["exposed_exchange_ms"] >= 0 for v in out["reserve_cus_trial"].values())
 
 
 @pytest.mark.gpu
@@ -61,6 +64,13 @@ def test_single_gpu_line_has_roofline_and_config_variants():
     rf = out["roofline"]
     assert rf["bound"] == "fp64-valu" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert "traffic_source" in rf and out["dtype"] == "f64" and out["n_gpus"] == 1
+    # the same configurations on the SymPy-specified Euler system (north_star: "drops in unchanged"), in the driver-run line
+    oc = out["other_configs"]
+    for name in ("cfg2_sympy", "cfg4_sympy"):
+        assert "error" not in oc[name], oc[name]
+        assert oc[name]["finite"] and oc[name]["value"] > 0 and "UserPDE" in oc[name]["roofline"]["kernel"] and oc[name]["vs_builtin_term_set"] > 0.5
+        assert "SymPy" in oc[name]["term_set"]
+    assert oc["cfg4"]["roofline"]["bound"] == "fp64 (valu+mfma)"
     for cfg, bound in (("cfg1", "hbm"), ("fv-ref", "hbm")):
         r = subprocess.run([sys.executable, BENCH, "--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=_env(),
                            capture_output=True, text=True, timeout=900)

@@ -126,10 +126,25 @@ def test_limiter_capacity_and_device_resident_mask():
     lim3.step(dt, mask)
     fewer = mask.copy()
     fewer[3, 3] = False
-    lim3.step(dt, fewer)
-    with pytest.raises(RuntimeError, match="capacity"):
-        lim3.check(wait=True)
+    try:                                                  # step() itself reports an overflow of a step the GPU has already completed
+        lim3.step(dt, fewer)
+        with pytest.raises(RuntimeError, match="capacity"):
+            lim3.check(wait=True)
+    except RuntimeError as e:
+        assert "capacity" in str(e)
     lim3.check(wait=True)
+    # ... and nobody has to ask: once the GPU is past an overflowing step, the next step() raises; reading the result back waits and raises
+    s4 = exa.AderDgSolver(dim, N, nc, dx=dx)
+    lim4 = exa.SubcellLimiter(s4, capacity=2)
+    s4.upload(u)
+    lim4.step(dt, mask)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="capacity"):
+        lim4.step(dt, fewer)
+    lim4.step(dt, mask)
+    with pytest.raises(RuntimeError, match="capacity"):
+        lim4.download()
+    assert lim4.download().shape == u.shape
     # default capacity: a bounded share of the block, not the block
     big = exa.AderDgSolver(2, 3, (40, 40))
     assert exa.SubcellLimiter(big).capacity == 160

@@ -759,7 +759,8 @@ def coupled_xt_ncp_system(max_dim=3, with_ncp=True, with_xt=True):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim,N,nc,with_ncp,with_xt", [(2, 3, (3, 2), False, True), (2, 4, (2, 3), True, True), (3, 3, (2, 2, 2), True, True),
-                                                         (3, 6, (2, 1, 2), True, True), (3, 4, (1, 2, 2), True, False), (2, 8, (2, 2), True, True)])
+                                                         (3, 6, (2, 1, 2), True, True), (3, 4, (1, 2, 2), True, False), (2, 8, (2, 2), True, True),
+                                                         (3, 2, (2, 2, 2), True, True), (2, 2, (3, 2), True, True)])     # N < dim + 1: qbar | Fbar_a need more LDS than N levels
 def test_aderdg_position_time_and_ncp_vs_numpy_oracle(dim, N, nc, with_ncp, with_xt):
     """ADER-DG for q_t + div F(q, x, t) + B(q, x, t) . grad q = S(q, x, t): node coordinates and level times reach the terms, the ncp enters the
     predictor, the time-averaged update and the Riemann solve.  Against oracle/aderdg_numpy.py step_xt with the SAME lambdified expressions
