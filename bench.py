@@ -518,6 +518,81 @@ def run_fv_ref(a, torch, exa, local):
     return out
 
 
+def run_fv_grid(a, torch, exa, local):
+    """SURVEY.md 8(f)-3, the steps either side of the FV kernel: a periodic Cartesian grid of patches advanced by FVPatchGrid -- halo states
+    taken from the neighbours inside the patch kernel (exa_fv_grid_step_device), CFL scan on the device, one host read per step -- next to the
+    BARE patch kernel on the same array (no halo fill, fixed dt), for the reference's patch shape and for cfg 4's limiter patch."""
+    shapes = {"ref-4x4": dict(dim=2, grid=(1024, 1024), P=4, n_aux=5, pde=exa.PDE_EULER_REF2D),
+              "limiter-15^3": dict(dim=3, grid=(16, 16, 32), P=15, n_aux=0, pde=exa.PDE_EULER)}
+    steps, warm = max(a.steps, 10), max(a.warmup, 3)
+    out_shapes = {}
+    for name, c in shapes.items():
+        dim, grid, P, V = c["dim"], c["grid"], c["P"], 5 + c["n_aux"]
+        fv = exa.FVPatchGrid(dim, grid, P, 1, 5, c["n_aux"], c["pde"], exa.FV_RUSANOV, device=local)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(3)
+        U = fv.U
+        U.copy_(torch.rand(U.shape, generator=g, device="cuda", dtype=torch.float64))
+        U[..., 0] += 1.0
+        U[..., 1:4] *= 0.2
+        U[..., 3 if dim == 2 else 4] += 3.0
+        fv.invalidate()
+        n_patches = int(torch.tensor(grid).prod())
+        vols = n_patches * P ** dim
+        S = P + 2
+        b_alg = vols * 16 * V                                        # every state read once, written once (halo-less arrays)
+        b_bare = vols * (8 * V * (S / P) ** dim + 8 * 5)             # the bare kernel on the reference layout: patch + halo read, n_real written
+        dt = 0.2 * fv.h / dim / fv.max_eigenvalue()
+
+        def timed(fn, n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        # the bare patch kernel: in place on the reference layout (array with halo), whatever the halo layers hold, fixed dt
+        two = exa.FVPatchGrid(dim, grid, P, 1, 5, c["n_aux"], c["pde"], exa.FV_RUSANOV, device=local, fused=False)
+        two.set_interior(fv.U)
+        two.fill_halos()
+        bare = lambda: two.kernel.time_step(two.Q, 0.05 * dt, two.h)
+        timed(bare, warm)
+        t_bare = timed(bare, steps)
+        two.set_interior(fv.U)
+        timed(lambda: two.step(0.05 * dt), 2)
+        t_two = timed(lambda: two.step(0.05 * dt), max(3, steps // 3))
+        del two
+        torch.cuda.empty_cache()
+        timed(lambda: fv.step(0.05 * dt), warm)
+        t_step = timed(lambda: fv.step(0.05 * dt), steps)
+        t_cfl = timed(lambda: (fv.invalidate(), fv.max_eigenvalue_device()), steps)
+
+        def cfl_step():
+            lam = fv.max_eigenvalue()                                            # left on the device by the previous step + the step's one host read
+            fv.step(min(0.05 * dt, 0.2 * fv.h / dim / lam))
+        timed(cfl_step, 2)
+        t_full = timed(cfl_step, steps)
+        out_shapes[name] = {"patches": n_patches, "patch_size": P, "variables": V, "bare_kernel_ms": 1e3 * t_bare, "grid_step_ms": 1e3 * t_step,
+                            "cfl_scan_ms": 1e3 * t_cfl, "step_with_cfl_ms": 1e3 * t_full, "step_with_cfl_over_bare": t_full / t_bare,
+                            "grid_step_over_bare": t_step / t_bare, "two_pass_torch_fill_ms": 1e3 * t_two,
+                            "volume_updates_per_s": vols / t_full, "algorithmic_gbs": b_alg / t_step / 1e9,
+                            "frac_of_hbm_peak": b_alg / t_step / 1e9 / HBM_PEAK_GBS, "bare_kernel_algorithmic_gbs": b_bare / t_bare / 1e9,
+                            "finite": bool(torch.isfinite(fv.interior_device()).all().item())}
+        del fv, U
+        torch.cuda.empty_cache()
+    r = out_shapes["ref-4x4"]
+    return {"metric": "DoF-updates/sec, FV patch GRID step (halo states from the neighbours inside the patch kernel + device CFL scan), 1 MI355X",
+            "value": r["volume_updates_per_s"] * 5, "unit": "DoF-updates/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+            "ms_per_step": r["step_with_cfl_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "periodic grid of FV Rusanov patches advanced by FVPatchGrid (SURVEY.md 8(f)-3): 2^20 patches 4x4 (5+5 variables) "
+                                   "and 8192 patches 15^3 (5 variables); per step: CFL scan (device) + one host read + the fused halo/update launch"},
+            "finite": all(v["finite"] for v in out_shapes.values()),
+            "roofline": {"kernel": "fv_rusanov_kernel<..., GRID> (4x4) / fv_rusanov_slab_kernel<..., GRID> (15^3)", "bound": "hbm",
+                         "bound_basis": "algorithmic bytes of the halo-less arrays (every state read once, written once: 16 V B per volume)", "achieved": r["algorithmic_gbs"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac_of_hbm_peak"], "traffic": None},
+            "shapes": out_shapes}
+
+
 def nccl_options():
     import torch.distributed as dist
     return dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
@@ -528,7 +603,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg1", "cfg4", "fv-ref", "cfg2_sympy", "cfg4_sympy"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg1", "cfg4", "fv-ref", "fv-grid", "cfg2_sympy", "cfg4_sympy"])
     ap.add_argument("--cells", type=int, default=128, help="cells per axis per GPU (default: BASELINE configs[2])")
     ap.add_argument("--order", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -603,13 +678,15 @@ def main():
                 return sympy_euler().register()                 # (JIT-compiled by hipcc on first use; __graft_entry__.build() prebuilds it in-tree)
             runs = (("cfg2_sympy", lambda: run_cfg2(b2, torch, exa, 1, 0, local, pde=sympy_id())), ("cfg1", lambda: run_cfg1(b, torch, exa, local)),
                     ("cfg4", lambda: run_cfg4(b, torch, exa, local)), ("cfg4_sympy", lambda: run_cfg4(b, torch, exa, local, pde=sympy_id())),
-                    ("fv-ref", lambda: run_fv_ref(b, torch, exa, local)))
+                    ("fv-ref", lambda: run_fv_ref(b, torch, exa, local)), ("fv-grid", lambda: run_fv_grid(b, torch, exa, local)))
             for name, fn in runs:
                 try:
                     r = fn()
                     others[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "finite", "roofline")}
                     others[name]["workload"] = r["config"]["workload"]
                     others[name]["term_set"] = r["config"].get("term_set")
+                    if "shapes" in r:
+                        others[name]["shapes"] = r["shapes"]
                     base = out if name == "cfg2_sympy" else others.get("cfg4") if name == "cfg4_sympy" else None
                     if base and "value" in base:
                         others[name]["vs_builtin_term_set"] = r["value"] / base["value"]
@@ -622,6 +699,8 @@ def main():
         out = run_cfg2(a, torch, exa, world, rank, local, pde=sympy_euler().register())
     elif a.config == "cfg4_sympy":
         out = run_cfg4(a, torch, exa, local, pde=sympy_euler().register())
+    elif a.config == "fv-grid":
+        out = run_fv_grid(a, torch, exa, local)
     elif a.config == "cfg1":
         out = run_cfg1(a, torch, exa, local)
     elif a.config == "cfg4":

@@ -41,15 +41,21 @@ struct UserPde {
     const DgLaunchTable* dg[4];
     int nv;
     int flags;             // EXA_PDE_FLAG_*
-    int (*fv)(int, int, int, int, int, int, long, double*, double, double, const long*, void*, double*, const double*, double);
+    int (*fv)(int, int, int, int, int, int, long, double*, double, double, const long*, void*, double*, const double*, double, const void*);
+    int (*fvmax)(int, int, int, int, int, long, const double*, double*, void*, const double*, double, double);
     int (*ev)(int, long, int, const double*, double*, double*, void*, const double*, double);
 };
 static std::vector<UserPde> g_user;
 
 int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                   double h, const long* slot, hipStream_t s, double* out, const double* centre, double t) {
+                   double h, const long* slot, hipStream_t s, double* out, const double* centre, double t, const FvGridArgs* grid) {
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].fv) { set_error("pde %d is not registered", pde); return -1; }
-    return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, (void*)s, out, centre, t);
+    return g_user[pde - 100].fv(mode, dim, P, H, n_real, n_aux, n_patches, Q, dt, h, slot, (void*)s, out, centre, t, grid);
+}
+int user_fv_maxeig(int pde, int dim, int P, int H, int n_real, int n_aux, long n_patches, const double* Q, double* lam, hipStream_t s,
+                   const double* centre, double t, double h) {
+    if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].fvmax) { set_error("pde %d is not registered", pde); return -1; }
+    return g_user[pde - 100].fvmax(dim, P, H, n_real, n_aux, n_patches, Q, lam, (void*)s, centre, t, h);
 }
 int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s, const double* X, double t) {
     if (pde - 100 >= (int)g_user.size() || !g_user[pde - 100].ev) { set_error("pde %d is not registered", pde); return -1; }
@@ -126,6 +132,7 @@ int exa_register_pde(const char* library_path, int* pde_id) {
     }
     int (*nvf)() = (int (*)())dlsym(h, "exa_user_nv");
     u.fv = (decltype(u.fv))dlsym(h, "exa_user_fv_launch");
+    u.fvmax = (decltype(u.fvmax))dlsym(h, "exa_user_fv_maxeig");
     u.ev = (decltype(u.ev))dlsym(h, "exa_user_pde_eval");
     if (!nvf || (!u.dg[2] && !u.dg[3] && !u.fv)) { dlclose(h); set_error("%s exports no exahype_amd PDE entry points", library_path); return EXA_ERR_INVALID; }
     u.nv = nvf();
@@ -222,6 +229,36 @@ int exa_fv_time_step_device_at(exa_fv_plan* p, double* Q_dev, const double* cent
     if (rc) return rc;
     return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, dt, h, nullptr, (hipStream_t)stream, nullptr,
                      centre_dev, t);
+}
+
+int exa_fv_grid_step_device(exa_fv_plan* p, const double* Q_dev, double* QNext_dev, const long* grid, const double* boundary_dev,
+                            const double* centre_dev, double t, double dt, double h, double* lambda_next_dev, void* stream) {
+    if (!p || !grid || ((!Q_dev || !QNext_dev) && p->count > 0)) { set_error("exa_fv_grid_step_device: NULL argument"); return EXA_ERR_INVALID; }
+    if (Q_dev == QNext_dev) { set_error("exa_fv_grid_step_device: the new states need an array of their own (the neighbours read the old ones)"); return EXA_ERR_INVALID; }
+    if (p->mode == EXA_FV_RUSANOV && !(h > 0.0)) { set_error("EXA_FV_RUSANOV needs the volume size h > 0"); return EXA_ERR_INVALID; }
+    FvGridArgs ga{QNext_dev, boundary_dev, {1, 1, 1}, lambda_next_dev};
+    long n = 1;
+    for (int a = 0; a < p->dim; a++) {
+        if (grid[a] < 1 || grid[a] > 0x7fffffffL) { set_error("exa_fv_grid_step_device: grid[%d] = %ld", a, grid[a]); return EXA_ERR_INVALID; }
+        ga.g[a] = (int)grid[a];
+        n *= grid[a];
+    }
+    if (n != p->n_patches) { set_error("exa_fv_grid_step_device: the grid has %ld patches, the plan %ld", n, p->n_patches); return EXA_ERR_INVALID; }
+    if (p->H > p->P) { set_error("exa_fv_grid_step_device: halo_size %d exceeds patch_size %d (the halo would reach past the face neighbour)", p->H, p->P); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, const_cast<double*>(Q_dev), dt, h, nullptr,
+                     (hipStream_t)stream, nullptr, centre_dev, t, &ga);
+}
+
+int exa_fv_max_eigenvalue(exa_fv_plan* p, const double* Q_dev, int halo_less, const double* centre_dev, double t, double h, double* lambda_dev,
+                          void* stream) {
+    if (!p || !lambda_dev || (!Q_dev && p->count > 0)) { set_error("exa_fv_max_eigenvalue: NULL argument"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    // (a halo-less array is a patch array with halo_size 0: every volume is an interior volume)
+    return fv_maxeig_launch(p->dim, p->P, halo_less ? 0 : p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, lambda_dev, (hipStream_t)stream,
+                            centre_dev, t, h);
 }
 
 long exa_fv_qout_count(const exa_fv_plan* plan) {

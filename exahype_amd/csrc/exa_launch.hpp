@@ -63,15 +63,29 @@ const DgLaunchTable* dg_launch_table(int dim, int pde);
 // fv_rusanov.hip
 // slot: nullptr, or one entry per patch (< 0: patch not in use, left untouched)
 // out != nullptr: out of place (QOut halo-less, [patch][P^dim][n_real + n_aux]); centre: [patch][dim] cell centres or nullptr; t: time
+// grid != nullptr: the GRID step -- the patches are the cells of a Cartesian grid g[0] x g[1] (x g[2]) (row-major), halo states are taken from the
+// face neighbours' interiors (or bstate[(axis * 2 + side) * V ..] on a domain face; null = periodic), results go to grid->out (layout of Q)
+struct FvGridArgs {
+    double* out;
+    const double* bstate;
+    int g[3];
+    double* lam;          // optional: receives the largest eigenvalue of the NEW interior states (zeroed by fv_launch on the stream)
+};
 int fv_launch(int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, double* Q, double dt,
-              double h, const long* slot, hipStream_t s, double* out = nullptr, const double* centre = nullptr, double t = 0.0);
+              double h, const long* slot, hipStream_t s, double* out = nullptr, const double* centre = nullptr, double t = 0.0,
+              const FvGridArgs* grid = nullptr);
+// max over the INTERIOR volumes of all patches and the directions of the largest eigenvalue -> lam[0] (device); centre / t / h as above
+int fv_maxeig_launch(int dim, int P, int H, int n_real, int n_aux, long n_patches, int pde, const double* Q, double* lam, hipStream_t s,
+                     const double* centre, double t, double h);
 // X: [n][3] positions (term sets that depend on position / time) or null; t: time
 int pde_eval_launch(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s, const double* X = nullptr,
                     double t = 0.0);
 
 // user PDE term sets registered at run time (capi.cpp: exa_register_pde), pde ids >= 100
 int user_fv_launch(int pde, int mode, int dim, int P, int H, int n_real, int n_aux, long n_patches, double* Q, double dt,
-                   double h, const long* slot, hipStream_t s, double* out, const double* centre, double t);
+                   double h, const long* slot, hipStream_t s, double* out, const double* centre, double t, const FvGridArgs* grid);
+int user_fv_maxeig(int pde, int dim, int P, int H, int n_real, int n_aux, long n_patches, const double* Q, double* lam, hipStream_t s,
+                   const double* centre, double t, double h);
 int user_pde_eval(int pde, int normal, long n, int stride, const double* Q, double* F, double* lam, hipStream_t s, const double* X, double t);
 
 void set_error(const char* fmt, ...);

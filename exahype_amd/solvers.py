@@ -644,12 +644,20 @@ def fill_halos_dirichlet(Q, grid, dim, patch_size, halo_size, boundary):
 
 
 class FVPatchGrid:
-    """A Cartesian grid of FV patches resident in HBM, advanced by the fused Rusanov kernel:
-    halo fill (periodic, or Dirichlet with `boundary=`) -> `time_step` for every patch -> ... ; dt from the CFL
-    condition when asked."""
+    """A Cartesian grid of FV patches resident in HBM, advanced by the fused Rusanov kernel -- the role of the enclave task around the
+    generated `time_step` (reference `exahype/printers/CPPPrinter.py:346`; the patch loop of `Unit test/correctness_test.cpp:118-174`).
+
+    The states live HALO-LESS, `self.U` [g0, g1, (g2,) P, P, (P,) V] (as Peano keeps its patches); step(dt) is ONE launch
+    (`exa_fv_grid_step_device`): the patch kernel assembles the patch with halo on chip, taking the states beyond a patch face from the face
+    neighbour's interior layers (periodic wrap, or the prescribed state on a domain face with `boundary=`), and writes the new states to a
+    second array; the two swap (`self.U` is rebound: fetch it again after a step).  No halo pass and no halo bytes in HBM.  run(t_end) takes dt
+    from the CFL condition: the kernel that writes the new states reduces their eigenvalues on the way, so a step costs ONE host read of one
+    double and no scan pass.  `Q` (property) materialises the reference layout with halo -- interiors + filled halo layers -- for a caller who
+    wants it (output, the plain `time_step` entry points).  fused=False keeps the two-pass form on an array with halo (halo fill by torch ops,
+    then the in-place update): the comparison the tests and the benchmark use."""
 
     def __init__(self, dim, grid, patch_size, halo_size=1, n_real=5, n_aux=0, pde=PDE_EULER, mode=FV_RUSANOV,
-                 length=1.0, device=0, boundary=None, origin=None, time=0.0):
+                 length=1.0, device=0, boundary=None, origin=None, time=0.0, fused=True):
         """origin, time: physical coordinates of the grid's low corner and the start time -- reach term sets whose terms depend on position /
         time (the patch centres follow from them); step() / run() advance the time."""
         torch = _torch()
@@ -658,67 +666,128 @@ class FVPatchGrid:
         self.h = length / (self.grid[0] * patch_size)                  # volume size
         n_patches = int(np.prod(self.grid))
         self.kernel = FVRusanovKernel(dim, patch_size, halo_size, n_real, n_aux, n_patches, pde, mode, device)
-        S = patch_size + 2 * halo_size
-        self.Q = torch.zeros(self.grid + (S,) * dim + (n_real + n_aux,), dtype=torch.float64,
-                             device=torch.device("cuda", device))
+        self.lib = self.kernel.lib
+        self.dev = torch.device("cuda", device)
+        self.fused = bool(fused)
+        V = n_real + n_aux
+        if self.fused:
+            self.U = torch.zeros(self.grid + (patch_size,) * dim + (V,), dtype=torch.float64, device=self.dev)
+            self._U2 = None                                           # the other array of the step (allocated on first use)
+        else:
+            S = patch_size + 2 * halo_size
+            self._Q = torch.zeros(self.grid + (S,) * dim + (V,), dtype=torch.float64, device=self.dev)
         self.time = float(time)
         self.boundary = boundary                                      # None: periodic
+        self._bstate = None
+        if boundary is not None:                                      # [2 dim][V]: state of the domain face (axis, side)
+            b = np.zeros((2 * dim, V))
+            for a in range(dim):
+                for side in range(2):
+                    b[a * 2 + side] = np.broadcast_to(np.asarray(boundary[(a, side)] if isinstance(boundary, dict) else boundary, dtype=np.float64), (V,))
+            self._bstate = torch.as_tensor(b).to(self.dev).contiguous()
+            # the prescribed states take part in the CFL scan (they sit in the halo layers a two-pass driver would scan); term sets that
+            # depend on position / time: at the origin and t = 0 -- a bound the caller may tighten through `cfl`
+            self._lam_boundary = max(float(np.max(pde_eval(pde, d, b)[1])) for d in range(dim))
         og = [float(x) for x in (origin if origin is not None else [0.0] * dim)]
         idx = np.stack(np.meshgrid(*[np.arange(g) for g in self.grid], indexing="ij"), axis=-1).reshape(-1, dim)
-        self.centres = torch.as_tensor(np.asarray(og)[None, :] + (idx + 0.5) * patch_size * self.h, dtype=torch.float64).to(self.Q.device).contiguous()
+        self.centres = torch.as_tensor(np.asarray(og)[None, :] + (idx + 0.5) * patch_size * self.h, dtype=torch.float64).to(self.dev).contiguous()
+        self._lam = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self._lam_next = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self._lam_valid = False                                       # _lam holds the scan of the CURRENT states (left there by the last fused step)
+        self._grid_arr = larr(list(self.grid))
+
+    # -- the reference layout (with halo) ----------------------------------------------------------
+    def _inner(self):
+        H, P = self.H, self.P
+        return (slice(None),) * self.dim + (slice(H, H + P),) * self.dim
+
+    @property
+    def Q(self):
+        """[g.., S.., V] with halo (S = P + 2 H).  fused: a COPY with the halo layers filled from the neighbours / the boundary states;
+        two-pass form: the array itself (halo layers as the last fill left them)."""
+        if not self.fused:
+            return self._Q
+        torch = _torch()
+        S = self.P + 2 * self.H
+        Q = torch.zeros(self.grid + (S,) * self.dim + (self.n_real + self.n_aux,), dtype=torch.float64, device=self.dev)
+        Q[self._inner()] = self.U
+        if self.boundary is None:
+            fill_halos_periodic(Q, self.grid, self.dim, self.P, self.H)
+        else:
+            fill_halos_dirichlet(Q, self.grid, self.dim, self.P, self.H, self.boundary)
+        return Q
 
     def fill_halos(self):
+        """two-pass form only: the halo layers of the array with halo from the neighbours' interiors / the boundary states (torch ops)"""
+        if self.fused:
+            return
         if self.boundary is None:
-            fill_halos_periodic(self.Q, self.grid, self.dim, self.P, self.H)
+            fill_halos_periodic(self._Q, self.grid, self.dim, self.P, self.H)
         else:
-            fill_halos_dirichlet(self.Q, self.grid, self.dim, self.P, self.H, self.boundary)
+            fill_halos_dirichlet(self._Q, self.grid, self.dim, self.P, self.H, self.boundary)
 
     def set_interior(self, values):
         """values: [g.., P.., V] (numpy or tensor)."""
         torch = _torch()
-        H, P = self.H, self.P
-        sl = (slice(None),) * self.dim + (slice(H, H + P),) * self.dim
-        self.Q[sl] = torch.as_tensor(np.asarray(values), dtype=torch.float64).to(self.Q.device)
+        self._lam_valid = False
+        v = torch.as_tensor(np.asarray(values) if not isinstance(values, torch.Tensor) else values, dtype=torch.float64).to(self.dev)
+        if self.fused:
+            self.U.copy_(v.reshape(self.U.shape))
+        else:
+            self._Q[self._inner()] = v
+
+    def interior_device(self):
+        return self.U if self.fused else self._Q[self._inner()]
 
     def interior(self):
-        H, P = self.H, self.P
-        return self.Q[(slice(None),) * self.dim + (slice(H, H + P),) * self.dim].cpu().numpy()
+        return self.interior_device().cpu().numpy()
+
+    def max_eigenvalue_device(self):
+        """Largest eigenvalue over the (interior) volumes and the directions at the current time: a 1-element CUDA tensor, no host
+        synchronisation.  After a fused step() it is already there -- the patch kernel reduced the eigenvalues of the states it wrote --
+        otherwise one reduction launch (`exa_fv_max_eigenvalue`).  (Whoever writes `self.U` directly calls invalidate().)"""
+        if not self._lam_valid:
+            arr = self.U if self.fused else self._Q
+            check(self.lib.exa_fv_max_eigenvalue(self.kernel._plan, C.c_void_p(arr.data_ptr()), 1 if self.fused else 0,
+                                                 C.c_void_p(self.centres.data_ptr()), self.time, self.h, C.c_void_p(self._lam.data_ptr()), _stream_ptr()))
+            if self._bstate is not None:
+                self._lam.clamp_(min=self._lam_boundary)
+            self._lam_valid = True
+        return self._lam
+
+    def invalidate(self):
+        """the states were written from outside: the next CFL scan reads the array again"""
+        self._lam_valid = False
 
     def max_eigenvalue(self):
-        lib = _lib.load()
-        torch = _torch()
-        flat = self.Q.reshape(-1, self.n_real + self.n_aux)
-        if _sees_position_and_time(lib, self.pde):
-            if getattr(self, "_xvol", None) is None:                   # volume centres of the array with halo (exahype2::fv::getVolumeCentre)
-                S = self.P + 2 * self.H
-                off = (torch.arange(S, dtype=torch.float64, device=self.Q.device) - self.H + 0.5 - 0.5 * self.P) * self.h
-                X = torch.zeros((self.centres.shape[0],) + (S,) * self.dim + (3,), dtype=torch.float64, device=self.Q.device)
-                for a in range(self.dim):
-                    sh = [1] * (1 + self.dim)
-                    sh[1 + a] = S
-                    X[..., a] = self.centres[:, a].reshape((-1,) + (1,) * self.dim) + off.reshape(sh)
-                self._xvol = X.reshape(-1, 3).contiguous()
-            return float(_max_eigenvalue_at(lib, self.pde, self.dim, flat, self._xvol, self.time)[0])
-        lam = torch.zeros(flat.shape[0], dtype=torch.float64, device=self.Q.device)
-        best = 0.0
-        for d in range(self.dim):
-            check(lib.exa_pde_eval_device(self.pde, d, flat.shape[0], flat.shape[1], C.c_void_p(flat.data_ptr()), None,
-                                          C.c_void_p(lam.data_ptr()), _stream_ptr()))
-            best = max(best, float(lam.max()))
-        return best
+        return float(self.max_eigenvalue_device()[0])
 
     def step(self, dt):
-        self.fill_halos()
-        self.kernel.time_step(self.Q, dt, self.h, t=self.time, centres=self.centres)
+        if not self.fused:
+            self.fill_halos()
+            self.kernel.time_step(self._Q, dt, self.h, t=self.time, centres=self.centres)
+            self.time += dt
+            self._lam_valid = False
+            return
+        torch = _torch()
+        if self._U2 is None:
+            self._U2 = torch.empty_like(self.U)
+        check(self.lib.exa_fv_grid_step_device(self.kernel._plan, C.c_void_p(self.U.data_ptr()), C.c_void_p(self._U2.data_ptr()), self._grid_arr,
+                                               C.c_void_p(self._bstate.data_ptr()) if self._bstate is not None else None,
+                                               C.c_void_p(self.centres.data_ptr()), self.time, dt, self.h,
+                                               C.c_void_p(self._lam_next.data_ptr()), _stream_ptr()))
+        self.U, self._U2 = self._U2, self.U
+        self._lam, self._lam_next = self._lam_next, self._lam         # the scan of the new states, by the kernel that wrote them
+        if self._bstate is not None:
+            self._lam.clamp_(min=self._lam_boundary)
+        self._lam_valid = True
         self.time += dt
 
     def run(self, t_end, cfl=0.4, max_steps=1000000):
         steps = 0
         while self.time < t_end * (1 - 1e-14) and steps < max_steps:
-            self.fill_halos()
-            dt = min(cfl * self.h / (self.dim * self.max_eigenvalue()), t_end - self.time)
-            self.kernel.time_step(self.Q, dt, self.h, t=self.time, centres=self.centres)
-            self.time += dt
+            dt = min(cfl * self.h / (self.dim * self.max_eigenvalue()), t_end - self.time)       # (the step's one host read)
+            self.step(dt)
             steps += 1
         return steps
 

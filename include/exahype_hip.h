@@ -120,6 +120,24 @@ int exa_fv_time_step_device_oop(exa_fv_plan* plan, const double* QIn_dev, double
 int exa_fv_time_step_device_at(exa_fv_plan* plan, double* Q_dev, const double* centre_dev, double t, double dt, double h, void* stream);
 long exa_fv_qout_count(const exa_fv_plan* plan);
 
+/* The patch update WITH its halo fill, on HALO-LESS arrays: the plan's patches are the cells of a Cartesian grid (grid[dim] patches per axis,
+ * patch index row-major) and Q_dev / QNext_dev are [n_patches][P^dim][n_real+n_aux] (exa_fv_qout_count doubles each, the layout of the
+ * CellData flavour's QOut).  What the reference leaves to the caller before `time_step` -- Peano keeps patches without halo and its enclave
+ * task assembles QIn with halo from the neighbours' boundary layers (`exahype/printers/CPPPrinter.py:346`; the patch loop of
+ * `Unit test/correctness_test.cpp:118-174`) -- happens inside the launch: the kernel builds the patch with halo on chip (LDS), taking the states
+ * beyond a patch face from the face neighbour's interior layers in Q_dev (periodic wrap; boundary_dev != NULL: on a domain face the prescribed
+ * state boundary_dev[(axis * 2 + side) * (n_real + n_aux) ..]).  Q_dev is only read; QNext_dev (a different array) receives the new states --
+ * a driver swaps the two per step.  No halo pass, no halo bytes in HBM.  centre_dev, t as exa_fv_time_step_device_at.
+ * lambda_next_dev (device, 1 double, or NULL): receives the largest eigenvalue of the NEW states over the directions (evaluated at t + dt) --
+ * the CFL scan of the NEXT step, computed on the values the kernel holds in registers instead of by a pass of its own. */
+int exa_fv_grid_step_device(exa_fv_plan* plan, const double* Q_dev, double* QNext_dev, const long* grid, const double* boundary_dev,
+                            const double* centre_dev, double t, double dt, double h, double* lambda_next_dev, void* stream);
+/* CFL scan of a patch array: max over the INTERIOR volumes of all patches and over the directions of the largest eigenvalue -> lambda_dev[0]
+ * (device memory; one reduction launch, nothing returns to the host).  halo_less != 0: Q_dev is a halo-less array (every volume counts).
+ * centre_dev / t / h: for term sets whose terms depend on position / time. */
+int exa_fv_max_eigenvalue(exa_fv_plan* plan, const double* Q_dev, int halo_less, const double* centre_dev, double t, double h, double* lambda_dev,
+                          void* stream);
+
 /* ---- ADER-DG cell kernels ---------------------------------------------------- */
 /* N = order + 1 nodes per axis; n_vars must equal the PDE's variable count (5 for
  * both Euler sets, any 1..8 for advection); n_picard < 0 selects N iterations,

@@ -148,3 +148,71 @@ def test_dg_cfl_time_loop():
         ref = oracle.aderdg_step(ref, dt, s.dx, operators(N), 2, N, 5, oracle.PDE_EULER, N, nc)
         t += dt
     assert rel_err(s.download().reshape(-1), ref) < 1e-10
+
+
+def _grid_state(grid, P, V, seed, dim):
+    """Euler-like admissible states [g.., P.., V]"""
+    rng = np.random.default_rng(seed)
+    Q = np.zeros(tuple(grid) + (P,) * dim + (V,))
+    Q[..., 0] = 1.0 + 0.3 * rng.random(Q.shape[:-1])
+    for a in range(1, 4):
+        Q[..., a] = Q[..., 0] * (0.4 * rng.random(Q.shape[:-1]) - 0.2)
+    Q[..., 4] = 2.6 + 0.5 * rng.random(Q.shape[:-1])
+    if V > 5:
+        Q[..., 5:] = rng.random(Q.shape[:-1] + (V - 5,))
+    return Q
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,grid,P,H,n_aux,mode,dirichlet", [
+    (2, (64, 1024), 4, 1, 5, "faithful", False),    # the reference's shape: staged, persistent grid (>= 2048 blocks of 16 patches)
+    (2, (5, 3), 4, 1, 5, "faithful", True),         # same shape, few patches: staged, one pass; ragged last block, wraps inside a block
+    (2, (3, 4), 4, 1, 0, "rusanov", True),          # no auxiliary variables: per-volume writes
+    (2, (2, 3), 6, 2, 1, "rusanov", False),         # two halo layers, odd variable count
+    (2, (2, 2), 40, 1, 0, "rusanov", False),        # 1 600 volumes per patch: no LDS copy, the stencil reads the neighbour patch directly
+    (3, (2, 3, 2), 4, 1, 0, "rusanov", True),       # 3-D small patches, staged
+    (3, (3, 2, 2), 15, 1, 0, "rusanov", False),     # cfg 4's limiter patch: plane-streaming kernel, cached scalars
+    (3, (2, 2, 3), 15, 1, 0, "faithful", True),     # ... its faithful form, domain faces with prescribed states
+    (3, (1, 2, 1), 12, 1, 2, "rusanov", False),     # a grid extent of 1: the patch is its own neighbour
+])
+def test_grid_step_equals_halo_fill_plus_patch_update(dim, grid, P, H, n_aux, mode, dirichlet):
+    """exa_fv_grid_step_device (halo-less arrays; the states beyond a patch face taken from the neighbours inside the launch) is BIT-equal to
+    the two-pass form it replaces -- halo fill of an array with halo, then the in-place `time_step` -- for every kernel variant the dispatch
+    knows, periodic and with prescribed boundary states, over several steps (so the array swap is exercised)."""
+    from exahype_amd import solvers as exa
+    V = 5 + n_aux
+    pde = exa.PDE_EULER_REF2D if (dim == 2 and mode == "faithful") else exa.PDE_EULER
+    m = exa.FV_FAITHFUL if mode == "faithful" else exa.FV_RUSANOV
+    rng = np.random.default_rng(7)
+    bnd = None
+    if dirichlet:
+        bnd = {(a, s_): np.concatenate([[1.1 + 0.1 * a, 0.1, -0.05 * s_, 0.02, 2.8], rng.random(n_aux)]) for a in range(dim) for s_ in range(2)}
+    U0 = _grid_state(grid, P, V, 11, dim)
+    a = exa.FVPatchGrid(dim, grid, P, H, 5, n_aux, pde, m, boundary=bnd, fused=True)
+    b = exa.FVPatchGrid(dim, grid, P, H, 5, n_aux, pde, m, boundary=bnd, fused=False)
+    a.set_interior(U0); b.set_interior(U0)
+    assert a.U.shape == tuple(grid) + (P,) * dim + (V,)                       # no halo bytes in HBM
+    dt = 1e-3 if mode == "rusanov" else 1e-4
+    for k in range(3):
+        a.step(dt)
+        b.step(dt)
+        ia, ib = a.interior(), b.interior()
+        assert np.isfinite(ib).all()
+        assert np.array_equal(ia, ib), (k, float(np.nanmax(np.abs(ia - ib))))
+    assert abs(a.time - b.time) == 0.0
+    # the layout with halo on demand: interiors + the halo layers the two-pass form had filled for this step
+    b.fill_halos()
+    S = P + 2 * H
+    co = np.indices((S,) * dim)
+    read = sum(((co[x] < H) | (co[x] >= H + P)).astype(int) for x in range(dim)) <= 1        # (corners / edges: not part of the stencil)
+    assert np.array_equal(a.Q.cpu().numpy()[(slice(None),) * dim + (read,)], b.Q.cpu().numpy()[(slice(None),) * dim + (read,)])
+    # the CFL scan: left behind by the kernel that wrote the states == a scan pass over the array == the host maximum
+    lam_fused = a.max_eigenvalue()
+    a.invalidate()
+    lam_scan = a.max_eigenvalue()
+    q = a.interior().reshape(-1, V)
+    want = max(float(np.max(exa.pde_eval(pde, d, q)[1])) for d in range(dim))
+    if dirichlet:
+        want = max(want, max(float(np.max(exa.pde_eval(pde, d, np.stack(list(bnd.values())))[1])) for d in range(dim)))
+    assert lam_scan == want
+    assert abs(lam_fused - want) <= 1e-12 * want          # (the plane-streaming kernel evaluates it with its fast reciprocal / square root)
