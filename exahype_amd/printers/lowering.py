@@ -14,8 +14,12 @@ luck are checked here, and a state that fails one is refused (`UnrecognisedKerne
   * every array access of every statement lies inside its array for the whole loop range (the reference's own examples do
     not: `items[1]` is addressed with `patch - 1`, SURVEY.md Appendix B-6);
   * a statement that writes an array reads that array only at the index it writes (no loop-carried dependence);
-  * no opaque function: the reference resolves `Flux(...)` to the user's host C++ at link time (`Unit test/Functions.h:2-4`),
-    a device kernel cannot -- such statement lists go through the recognised schemes with `pde=` / SymPy bodies.
+  * no OPAQUE function: the reference resolves `Flux(...)` to the user's host C++ at link time (`Unit test/Functions.h:2-4`), a device
+    kernel cannot.  A function declared with a SymPy body (`kernel.function(name, ..., body=...)`) is lowered: the body becomes a
+    `__device__` function with the reference's calling convention -- array arguments by address (`&Q[...]`: the callee sees the
+    volume's variables from there on), a trailing array argument of a bare call is the out-parameter (`Flux(Q, normal, F)`,
+    `exahype/printers/CPPPrinter.py:152-155`), a directional constant arrives as the integer normal -- and the statement keeps the
+    reference's text (`CPPPrinter.py:204-276`).  `max(a, b)` of two scalars by address is `Unit test/Functions.cpp:64-66`.
 Integer powers, which SymPy builds from `a*a` and the reference prints as the Python `a**2`, are printed as products.
 """
 from __future__ import annotations
@@ -43,6 +47,11 @@ class LoweringRefused(NotImplementedError):
     """The builder state cannot be lowered statement by statement (reason in the message)."""
 
 
+def _default_max(a, b):
+    """`max(double* a, double* b)` of the reference's user functions (`Unit test/Functions.cpp:64-66`)"""
+    return sympy.Max(a[0], b[0])
+
+
 class _CText(StrPrinter):
     """str(expr) as the reference prints it, except a**n (n = 2..4), printed as the product it came from."""
 
@@ -63,6 +72,24 @@ class _CText(StrPrinter):
 
 def _ctext(expr):
     return _CText().doprint(expr) if isinstance(expr, sympy.Basic) else str(expr)
+
+
+class _CallText(_CText):
+    """C text of a statement side that calls functions, printed from the tree: array elements with the reference's flat index
+    (`CPPPrinter.Cppify` of the element alone), array arguments of a call by address -- once.  (The reference's text pass puts its `&` by
+    substring replacement over the item names, `exahype/printers/CPPPrinter.py:230-236`: `Flux(Q_copy` becomes `Flux(&&Q_copy` as soon as
+    `Q` is an item too, and an item named `F` gives `&Flux(`; what it MEANS is in its older output `Unit test/test.cpp:25`.)"""
+
+    def __init__(self, cpp, functions):
+        super().__init__()
+        self._cpp, self._functions = cpp, functions
+
+    def _print(self, expr, **kwargs):
+        if isinstance(expr, Indexed):
+            return self._cpp.Cppify(str(expr))
+        if isinstance(expr, sympy.Function) and type(expr).__name__ in self._functions:
+            return "%s(%s)" % (type(expr).__name__, ", ".join(("&" if isinstance(a, Indexed) else "") + self._print(a) for a in expr.args))
+        return StrPrinter._print(self, expr, **kwargs)
 
 
 class StatementLowering:
@@ -91,6 +118,7 @@ class StatementLowering:
             self.arrays[name] = (k.n_patches * size ** k.dim * leap, leap, size)
         self.primary = k.items[0]
         self.consts = list(k.inputs)
+        self.functions = {}               # name -> device function generated from the SymPy body (see _function)
         self.statements = []
         dconst = {}
         for n, (lhs, rhs, direction, span) in enumerate(zip(k.LHS, k.RHS, k.directions, k.struct_inclusion)):
@@ -105,22 +133,38 @@ class StatementLowering:
     def _analyse(self, n, lhs, rhs, direction, span, dconst):
         k = self.k
         where = "statement %d (`%s = %s`)" % (n, lhs, rhs)
+        bare = (rhs is None or (isinstance(rhs, str) and rhs == "")) and self._is_call(lhs)      # `Flux(Q, normal, F);`
+        calls = []
         for e in (lhs, rhs):
             if isinstance(e, sympy.Basic):
-                calls = [a for a in e.atoms(AppliedUndef)] + [a for a in e.atoms(sympy.Function) if type(a).__name__ in k.functions]
-                if calls or type(e).__name__ in k.functions:
-                    raise LoweringRefused("%s calls the opaque function `%s`: the reference resolves it to host C++ at link time; use a "
-                                          "recognised scheme with pde= / SymPy bodies" % (where, type((calls or [e])[0]).__name__))
-        if not isinstance(lhs, Indexed):
+                calls += [a for a in e.atoms(sympy.Function) if self._is_call(a)]
+        ptr_width = {}                                        # Indexed argument of a call -> doubles the callee touches from there
+        out_ptr = None
+        for c in calls:
+            f = self._function(c, bare and c is lhs, where, dconst)
+            for a, kind, width in zip(c.args, f["kinds"], f["widths"]):
+                if kind in ("in", "out"):
+                    ptr_width[a] = max(ptr_width.get(a, 1), width)
+                if kind == "out":
+                    out_ptr = a
+        if bare:
+            if out_ptr is None:
+                raise LoweringRefused("%s: a bare call needs an array out-parameter (its last array argument)" % where)
+        elif not isinstance(lhs, Indexed):
             raise LoweringRefused("%s: the left-hand side is not an array element" % where)
-        if rhs is None or (isinstance(rhs, str) and rhs == ""):
+        if not bare and (rhs is None or (isinstance(rhs, str) and rhs == "")):
             raise LoweringRefused("%s has no right-hand side" % where)
+        target = out_ptr if bare else lhs
         rng = self.cpp._ranges([lhs, rhs], direction, span)
         names = [str(i) for i in k.indexes]
         bounds = {nm: (lo, hi - 1) for nm, (lo, hi) in zip(names, rng)}
         var_loop = rng[-1][1] > 1
         # bounds of every access, dependence of the written array
-        accesses = [lhs] + (sorted(rhs.atoms(Indexed), key=str) if isinstance(rhs, sympy.Basic) else [])
+        reads = set()
+        for e in ((lhs, rhs) if not bare else (lhs,)):
+            if isinstance(e, sympy.Basic):
+                reads |= e.atoms(Indexed)
+        accesses = [target] + sorted((a for a in reads if a is not target), key=str)
         for a in accesses:
             base = str(a.base)
             if base not in self.arrays:
@@ -147,14 +191,25 @@ class StatementLowering:
                     lo, hi = lo + stride * (b[0] + off), hi + stride * (b[1] + off)
                 else:
                     lo, hi = lo + stride * int(ix), hi + stride * int(ix)
+            hi += ptr_width.get(a, 1) - 1                     # an array argument of a call: the callee touches `width` doubles from there
             if lo < 0 or hi >= total:
                 raise LoweringRefused("%s: `%s` reaches flat index %d .. %d of an array of %d doubles over the loop range -- out of "
                                       "bounds (the reference's text would read or write past its heap block)" % (where, a, lo, hi, total))
-            if a is not lhs and str(a.base) == str(lhs.base) and tuple(a.indices) != tuple(lhs.indices):
+            if a is not target and str(a.base) == str(target.base) and (tuple(a.indices) != tuple(target.indices) or a in ptr_width or target in ptr_width):
                 raise LoweringRefused("%s writes `%s` and reads it at another index (`%s`): a loop-carried dependence in the reference's "
-                                      "sequential loop nest, not reproducible by a parallel launch" % (where, lhs.base, a))
-        text_l = self.cpp.Cppify(lhs)
-        text_r = self.cpp.Cppify(_ctext(rhs))
+                                      "sequential loop nest, not reproducible by a parallel launch" % (where, target.base, a))
+        if bare and var_loop:
+            raise LoweringRefused("%s: a bare call inside a loop over the variables would run once per variable" % where)
+        for a, w in ptr_width.items():
+            if a is not out_ptr and str(a.base) == str(target.base) and (var_loop or tuple(a.indices) != tuple(target.indices)):
+                raise LoweringRefused("%s writes `%s` and hands it to a call by address (`&%s`, %d doubles from there): the lanes of the variable "
+                                      "loop write what the callee reads -- a loop-carried dependence in the reference's sequential loop nest, not "
+                                      "reproducible by a parallel launch" % (where, target.base, a, w))
+        if calls:
+            ct = _CallText(self.cpp, k.functions)
+            text_l, text_r = ct.doprint(lhs), ("" if bare else ct.doprint(rhs))
+        else:
+            text_l, text_r = self.cpp.Cppify(lhs), self.cpp.Cppify(_ctext(rhs))
         if not var_loop:
             text_l, text_r = text_l.replace(" + var", ""), text_r.replace(" + var", "")
         if "**" in text_r or re.search(r"(?<![\w.])\d+/\d+(?![\w.])", text_r):
@@ -163,13 +218,121 @@ class StatementLowering:
         for e in (lhs, rhs):
             if isinstance(e, sympy.Basic):
                 free |= {str(s) for s in e.free_symbols if isinstance(s, Symbol)}
-        unknown = free - set(names) - set(self.consts) - set(dconst) - {"dim", "patch_size", "halo_size", "n_real", "n_aux"}
+        unknown = free - set(names) - set(self.consts) - set(dconst) - {"dim", "patch_size", "halo_size", "n_real", "n_aux"} - set(k.functions)
         unknown = {u for u in unknown if u not in self.arrays}
         if unknown:
             raise LoweringRefused("%s uses %s, which is neither an input constant, a directional constant nor a builder constant"
                                   % (where, sorted(unknown)))
-        return {"n": n, "lhs": text_l, "rhs": text_r, "ranges": rng, "var_loop": var_loop,
-                "dconst": {nm: v for nm, v in dconst.items() if nm in free}, "writes": str(lhs.base)}
+        return {"n": n, "lhs": text_l, "rhs": text_r, "ranges": rng, "var_loop": var_loop, "bare_call": bare,
+                "dconst": {nm: v for nm, v in dconst.items() if nm in free}, "writes": str(target.base)}
+
+    # -- functions with SymPy bodies ---------------------------------------------------------------------
+    def _is_call(self, e):
+        return isinstance(e, sympy.Function) and type(e).__name__ in self.k.functions
+
+    def _function(self, call, is_bare, where, dconst):
+        """The `__device__` function behind a call, generated once per name from the SymPy body: parameter kinds from the call site (array
+        argument -> pointer; directional constant -> integer, the body is evaluated once per value; anything else -> double), the body's
+        expressions as C text with shared sub-expressions named."""
+        from ..pde_codegen import _DevicePrinter
+        k = self.k
+        name = type(call).__name__
+        body = k.function_bodies.get(name) or (_default_max if name == "max" else None)
+        if body is None:
+            raise LoweringRefused("%s calls the opaque function `%s`: the reference resolves it to host C++ at link time; give it a SymPy body "
+                                  "(kernel.function(..., body=...)) or use a recognised scheme with pde=" % (where, name))
+        kinds, widths = [], []
+        idx_args = [j for j, a in enumerate(call.args) if isinstance(a, Indexed)]
+        for j, a in enumerate(call.args):
+            if isinstance(a, Indexed):
+                base = str(a.base)
+                if base not in self.arrays:
+                    raise LoweringRefused("%s: `%s` is not a declared item" % (where, base))
+                leap = self.arrays[base][1]
+                kinds.append("out" if (is_bare and j == idx_args[-1]) else "in")
+                widths.append(min(leap, k.n_real))
+            elif isinstance(a, Symbol) and str(a) in k.directional_consts:
+                kinds.append("dir")
+                widths.append(0)
+            elif isinstance(a, sympy.Basic) and not a.atoms(Indexed):
+                kinds.append("num")
+                widths.append(0)
+            else:
+                raise LoweringRefused("%s: argument `%s` of `%s` is neither an array element, a directional constant nor a scalar expression" % (where, a, name))
+        if name in self.functions:
+            f = self.functions[name]
+            if f["kinds"] != kinds or (f["widths"] != widths and "out" not in kinds):
+                raise LoweringRefused("%s: `%s` is called with another argument pattern than before" % (where, name))
+            return f
+        dir_names = [str(a) for a, kd in zip(call.args, kinds) if kd == "dir"]
+        if len(dir_names) > 1:
+            raise LoweringRefused("%s: more than one directional constant in a call of `%s`" % (where, name))
+        values = [int(v) for v in k.directional_consts[dir_names[0]]] if dir_names else [None]
+        params, syms = [], []
+        for j, (kd, w) in enumerate(zip(kinds, widths)):
+            if kd == "in":
+                params.append("double* p%d" % j)                    # (non-const, as the reference declares them: `Unit test/Functions.h:2-4`; and an exact match beats the library templates of the same name, e.g. max)
+                syms.append([Symbol("p%d_%d" % (j, v), real=True) for v in range(w)])
+            elif kd == "out":
+                params.append("double* o%d" % j)
+                syms.append(None)
+            elif kd == "dir":
+                params.append("int n%d" % j)
+                syms.append("dir")
+            else:
+                params.append("double s%d" % j)
+                syms.append(Symbol("s%d" % j, real=True))
+        pr = _DevicePrinter()
+        rename = {}
+        for j, sy in enumerate(syms):
+            if isinstance(sy, list):
+                rename.update({x: Symbol("p%d[%d]" % (j, v)) for v, x in enumerate(sy)})
+        cases, n_out = {}, None
+        for val in values:
+            args = [(val if sy == "dir" else sy) for sy in syms if sy is not None]
+            try:
+                res = body(*args)
+            except TypeError as e:
+                raise LoweringRefused("%s: the body of `%s` does not take the call's arguments (%s)" % (where, name, e))
+            is_list = isinstance(res, (list, tuple))
+            if is_list != ("out" in kinds):
+                raise LoweringRefused("%s: `%s` %s" % (where, name, "returns a list of expressions: call it as a bare statement with an array out-parameter"
+                                                       if is_list else "returns one expression but is called as a bare statement"))
+            exprs = [sympy.sympify(e).xreplace(rename) for e in (res if is_list else [res])]
+            repl, red = sympy.cse(exprs, symbols=sympy.numbered_symbols("t_"))
+            cases[val] = {"temps": [(str(a), pr.doprint(b)) for a, b in repl], "results": [pr.doprint(e) for e in red]}
+            n_out = len(exprs)
+        if "out" in kinds:
+            widths[kinds.index("out")] = n_out
+        f = {"name": name, "kinds": kinds, "widths": widths, "params": params, "cases": cases, "returns": "void" if "out" in kinds else "double",
+             "dir_param": next((p.split()[-1] for p, kd in zip(params, kinds) if kd == "dir"), None),
+             "out_param": next((p.split()[-1] for p, kd in zip(params, kinds) if kd == "out"), None)}
+        self.functions[name] = f
+        return f
+
+    def functions_source(self):
+        out = []
+        for f in self.functions.values():
+            out.append("static __device__ inline %s %s(%s) {" % (f["returns"], f["name"], ", ".join(f["params"])))
+
+            def block(c, ind):
+                lines = ["%sconst double %s = %s;" % (ind, a, b) for a, b in c["temps"]]
+                if f["returns"] == "void":
+                    lines += ["%s%s[%d] = %s;" % (ind, f["out_param"], v, e) for v, e in enumerate(c["results"])]
+                else:
+                    lines.append("%sreturn %s;" % (ind, c["results"][0]))
+                return lines
+            if f["dir_param"] is None:
+                out += block(f["cases"][None], "    ")
+            else:
+                out.append("    switch (%s) {" % f["dir_param"])
+                for val, c in f["cases"].items():
+                    out += ["    case %d: {" % val] + block(c, "        ") + ["    } break;" if f["returns"] == "void" else "    }"]
+                out.append("    }")
+                if f["returns"] == "double":
+                    out.append("    return 0.0;")
+            out += ["}", ""]
+        return out
 
     # -- code ----------------------------------------------------------------------------------------------
     def array_order(self):
@@ -185,6 +348,7 @@ class StatementLowering:
                % self.name,
                "// ranges, AoS strides and expression text (exahype/printers/CPPPrinter.py:84-137); gfx950, -ffp-contract=off.",
                "#include <hip/hip_runtime.h>", "#include <cmath>", ""]
+        out += self.functions_source()
         lits = "".join("    const %s\n" % lit for lit in k.literals)
         for s in self.statements:
             rng = s["ranges"]
@@ -205,7 +369,7 @@ class StatementLowering:
                 body.append(lits.rstrip("\n"))
             for nm, v in s["dconst"].items():
                 body.append("    const double %s = %s;" % (nm, v))
-            body.append("    %s = %s;" % (s["lhs"], s["rhs"]))
+            body.append(("    %s;" % s["lhs"]) if s.get("bare_call") else ("    %s = %s;" % (s["lhs"], s["rhs"])))
             body.append("}")
             out += body + [""]
             s["total"] = total
