@@ -415,6 +415,10 @@ def run_cfg1(a, torch, exa, local):
                         "the fused kernel keeps the traces on chip, so its measured HBM rate (hbm_measured_gbs) is lower than `achieved`",
                         "hbm_measured_gbs": (traffic / tk / 1e9) if traffic else None, "achieved": b_alg / tk / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": b_alg / tk / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": b_alg / tk / 1e9 / HBM_MEASURED_GBS,
+                        # against the fused kernel's OWN compulsory traffic -- u read once, written once: 16 NV N^2 = 1 280 B per cell -- the kernel
+                        # is at a quarter of the HBM roof: it is LDS- / issue-bound, not memory-bound
+                        "compulsory_bytes_per_launch": 16 * 5 * N * N * nc[0] * nc[1],
+                        "frac_of_compulsory": 16 * 5 * N * N * nc[0] * nc[1] / tk / 1e9 / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": src, "launch_ms": tk * 1e3, "bytes_per_launch": b_alg}}
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_dg(2, N, 0, seconds=6.0)
