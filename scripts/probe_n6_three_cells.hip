@@ -1,0 +1,294 @@
+// Probe: would stage A of 3-D p = 5 gain from THREE cells in flight per CU (3 waves per SIMD) with one-level steps and the
+// derivative contraction on the matrix pipe -- the form that freed the registers at N = 8 (exa_dg_m8.hpp)?  Both forms run the three phases of a
+// Picard step on LDS-resident data with the owner state really live in registers (iterate + accumulators of all 6 levels: 120 VGPRs), so that
+// the compiler faces the register budget of the real kernel:
+//   form V (shipped, exa_dg_reg.hpp): 2 cells per CU = 2 x 256 threads, a step = TWO levels, [derive: one pencil per lane, vector even-odd
+//           contraction] barrier [fold of two levels + load of the next two], the halves one phase apart;
+//   form M: 3 cells per CU = 3 x 256 threads (<= 168 VGPRs), a step = ONE level, [derive: four lanes per pencil (three used: 9 / 16 of a
+//           v_mfma_f64_4x4x4_4b_f64 tile), 108 pencils = 7 wave tasks in two rounds] [fold] [load], the thirds one phase apart.
+// Figure of merit: time per (cell, level) -- V finishes 2 cell-levels per phase, M one.  Results of the two derive forms are compared.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I exahype_amd/csrc scripts/probe_n6_three_cells.hip -o scripts/bin/probe_n6
+// Run  : scripts/bin/probe_n6 [steps = 3000]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <random>
+#include <type_traits>
+#include <vector>
+#include "exa_pde.hpp"
+using namespace exa;
+
+constexpr int N = 6, H = 3, NV = 5, NA = 2, NVA = 7, NN = 216, NF = 36, SL = 217;
+__constant__ double c_E[H * N];             // DEO packing of the product kernels: [j][i] even part, [j][H + i] odd part
+__constant__ double c_T[N * N];             // -dt T[l'][l]
+__constant__ short c_tabV[256];             // form V: lane -> packed pencil task of a two-level step (d | ls << 2 | t << 3), -1 idle
+__constant__ short c_tabM[8 * 16];          // form M: [wave task][p] -> d | t << 2, -1 idle
+
+#define LD(i) (*(const volatile __attribute__((address_space(3))) double*)(&lds[i]))
+#define ST(i, v) *(volatile __attribute__((address_space(3))) double*)(&lds[i]) = (v)
+__host__ __device__ inline int pbase(int d, int t) { const int a = t / N, b = t % N; return d == 0 ? a * N + b : (d == 1 ? a * NF + b : a * NF + b * N); }
+__host__ __device__ inline int pstride(int d) { return d == 0 ? NF : (d == 1 ? N : 1); }
+
+// ---- owner phases (the same arithmetic in both forms; LV = levels per step).  LDS image of a cell: [slot][level slot][node], slots q (NV) | flux
+// scalars (NA) | S_x | S_y | S_z (NV each)
+template <int LV> struct Img {
+    static constexpr int VS = LV * SL, SOFF = NVA * VS, QSZ = NV * VS, CELL = SOFF + 3 * QSZ;
+};
+template <int LV, int L0> __device__ inline void fold(double* lds, int node, double (&acc)[N][NV], const double (&u)[NV]) {
+    using I = Img<LV>;
+    double S[LV][NV];
+#pragma unroll
+    for (int ls = 0; ls < LV; ls++)
+#pragma unroll
+        for (int v = 0; v < NV; v++)
+            S[ls][v] = LD(I::SOFF + v * I::VS + ls * SL + node) + (LD(I::SOFF + I::QSZ + v * I::VS + ls * SL + node) + LD(I::SOFF + 2 * I::QSZ + v * I::VS + ls * SL + node));
+#pragma unroll
+    for (int ls = 0; ls < LV; ls++)
+#pragma unroll
+        for (int lp = 0; lp < N; lp++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) acc[lp][v] = fma(c_T[(L0 + ls) * N + lp], S[ls][v], (L0 + ls == 0) ? u[v] : acc[lp][v]);
+}
+template <int LV, int L0> __device__ inline void load(double* lds, int node, const double (&q)[N][NV]) {
+    using I = Img<LV>;
+#pragma unroll
+    for (int ls = 0; ls < LV; ls++) {
+        double a[NA];
+        Euler::aux_fast(q[(L0 + ls) % N], a);
+#pragma unroll
+        for (int v = 0; v < NV; v++) ST(v * I::VS + ls * SL + node, q[(L0 + ls) % N][v]);
+#pragma unroll
+        for (int k = 0; k < NA; k++) ST((NV + k) * I::VS + ls * SL + node, a[k]);
+    }
+}
+
+template <int I_, int E_, class F> __device__ inline void sfor(F&& f) {
+    if constexpr (I_ < E_) { f(std::integral_constant<int, I_>{}); sfor<I_ + 1, E_>(f); }
+}
+
+// ---- form V derive: one pencil per lane, run-time direction (exa_dg_reg.hpp derive_a / derive_b)
+__device__ inline void derive_v(double* lds, int pk, double sc) {
+    using I = Img<2>;
+    if (pk < 0) return;
+    const int d = pk & 3, ls = (pk >> 2) & 1, t = pk >> 3;
+    const int off = ls * SL + pbase(d, t), ps = pstride(d), so = I::SOFF + d * I::QSZ;
+    Euler::Dir dir;
+    Euler::dir_init(dir, d, sc);
+    double e[H][NV], o[H][NV];
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        double qa[NVA], qb[NVA], Fa[NV], Fb[NV];
+#pragma unroll
+        for (int k = 0; k < NVA; k++) { qa[k] = LD(k * I::VS + off + j * ps); qb[k] = LD(k * I::VS + off + (N - 1 - j) * ps); }
+        Euler::flux_scaled_dir(qa, qa + NV, dir, Fa);
+        Euler::flux_scaled_dir(qb, qb + NV, dir, Fb);
+#pragma unroll
+        for (int v = 0; v < NV; v++) { e[j][v] = Fa[v] + Fb[v]; o[j][v] = Fa[v] - Fb[v]; }
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        double M[NV], sI[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) M[v] = c_E[H + i] * o[0][v];
+#pragma unroll
+        for (int j = 1; j < H; j++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) M[v] = fma(c_E[j * N + H + i], o[j][v], M[v]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) sI[v] = M[v];
+#pragma unroll
+        for (int j = 0; j < H; j++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) sI[v] = fma(c_E[j * N + i], e[j][v], sI[v]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            ST(so + v * I::VS + off + i * ps, sI[v]);
+            ST(so + v * I::VS + off + (N - 1 - i) * ps, fma(2.0, M[v], -sI[v]));
+        }
+    }
+}
+
+// ---- form M derive: four lanes per pencil (p = lane & 15, j = lane >> 4; j = 3 has no node pair at N = 6: it repeats pair 2 and feeds zeros)
+__device__ inline void derive_m(double* lds, int lane, int wtask, double sc0, double sc1, double sc2) {
+    using I = Img<1>;
+    if (c_tabM[wtask * 16] < 0) return;                               // no pencil in this wave task (wave-uniform)
+    const int pk0 = c_tabM[wtask * 16 + (lane & 15)];
+    const bool on = pk0 >= 0;                                         // a task padded with idle pencils: their lanes compute on the task's first
+    const int pk = on ? pk0 : c_tabM[wtask * 16];                     // pencil and store nothing (the matrix instruction runs on the whole wave)
+    const int d = pk & 3, t = pk >> 2, j = lane >> 4, jj = j < H ? j : H - 1;
+    const int off = pbase(d, t), ps = pstride(d), so = I::SOFF + d * I::QSZ;
+    const int ia = lane & 3;
+    const double aEe = (j < H && ia < H) ? c_E[jj * N + ia] : 0.0, aEo = (j < H && ia < H) ? c_E[jj * N + H + ia] : 0.0;   // A[i = lane & 3][k = j] (row 3, column 3: zero)
+    Euler::Dir dir;
+    Euler::dir_init(dir, d, d == 0 ? sc0 : (d == 1 ? sc1 : sc2));
+    double qa[NVA], qb[NVA], Fa[NV], Fb[NV];
+#pragma unroll
+    for (int k = 0; k < NVA; k++) { qa[k] = LD(k * I::VS + off + jj * ps); qb[k] = LD(k * I::VS + off + (N - 1 - jj) * ps); }
+    Euler::flux_scaled_dir(qa, qa + NV, dir, Fa);
+    Euler::flux_scaled_dir(qb, qb + NV, dir, Fb);
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const double e = j < H ? Fa[v] + Fb[v] : 0.0, o = j < H ? Fa[v] - Fb[v] : 0.0;
+        const double Pv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, e, 0.0, 0, 0, 0);     // P_{i = j} of pencil p
+        const double Mv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, o, 0.0, 0, 0, 0);
+        if (j < H && on) {
+            ST(so + v * I::VS + off + j * ps, Mv + Pv);
+            ST(so + v * I::VS + off + (N - 1 - j) * ps, Mv - Pv);
+        }
+    }
+}
+
+// FORM 0 = V (CPW cells of 256 threads, 2 levels per step, 2 phases), FORM 1 = M (1 level per step, 3 phases)
+template <int FORM, int CPW>
+__global__ void __launch_bounds__(256 * CPW) probe(const double* __restrict__ q0, double* __restrict__ out, int steps, double sc) {
+    constexpr int LV = FORM == 0 ? 2 : 1;                      // FORM 2: as 1 with fold + load in ONE phase (two barriers per level)
+    using I = Img<LV>;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
+    double* lds = lds_all + part * I::CELL;
+    const bool owner = tid < NN;
+    const int node = owner ? tid : 0;
+    // owner state: iterate and accumulators of all six levels, u
+    double q[N][NV], acc[N][NV], u[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) u[v] = q0[v * SL + node];
+#pragma unroll
+    for (int l = 0; l < N; l++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) { q[l][v] = u[v] * (1.0 + 1e-3 * l); acc[l][v] = u[v]; }
+    if (owner) load<LV, 0>(lds, node, q);
+    const int pkV = c_tabV[tid];
+    __syncthreads();
+    // the parts run the same program `part` phases apart (exa_dg_reg.hpp: CPW): barriers are the workgroup's, every part passes the same number
+    for (int p = 0; p < part; p++) __syncthreads();
+    for (int it = 0; it < steps; it++) {
+        sfor<0, N / LV>([&](auto sc_) {
+            constexpr int L0 = decltype(sc_)::value * LV;
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (FORM == 0) derive_v(lds, pkV, sc);
+            else {
+                derive_m(lds, lane, wave, sc, sc, sc);
+                derive_m(lds, lane, 4 + wave, sc, sc, sc);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            if (owner) fold<LV, L0>(lds, node, acc, u);
+            if constexpr (FORM == 1) __syncthreads();                  // (FORM 1: three phases per step)
+            if constexpr (L0 + LV >= N) {                              // end of an iteration: the accumulators are the new iterate
+#pragma unroll
+                for (int l = 0; l < N; l++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) q[l][v] = acc[l][v] * 1e-3 + u[v];          // (kept bounded: the probe iterates for thousands of steps)
+            }
+            if (owner) load<LV, (L0 + LV) % N>(lds, node, q);
+            __syncthreads();
+        });
+    }
+    for (int p = part; p < CPW - 1; p++) __syncthreads();
+    if (blockIdx.x == 0 && part == 0)
+        for (int k = tid; k < 3 * I::QSZ; k += 256) out[k] = lds[I::SOFF + k];
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < N; l++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) s += acc[l][v] + q[l][v];
+    if (s == 1.2345e300) out[tid] = s;
+}
+
+// lane tables: form V as dg_inst.hip fill_reg_tables (simplified: groups of one direction, residues distinct where they fit); form M: 16 pencils of
+// one direction per wave task whose bank residues keep the node pairs k, k + 1 of a 32-lane group apart (greedy)
+static void tables(short* tv, short* tm) {
+    for (int k = 0; k < 256; k++) tv[k] = -1;
+    int lane = 0;
+    for (int d = 0; d < 3; d++)
+        for (int ls = 0; ls < 2; ls++)
+            for (int t = 0; t < NF; t++) tv[lane++] = (short)(d | ls << 2 | t << 3);
+    // (plain order; the product kernel's table search removes most of the conflicts this leaves -- the same handicap for both forms' owner phases)
+    for (int k = 0; k < 8 * 16; k++) tm[k] = -1;
+    // all 108 pencils in one pool (the direction is a per-lane run-time value): seven tasks of 16, each filled with pencils whose residues of node
+    // pair k and k + 1 are free; what is left at the end goes into the holes, conflicts or not
+    std::vector<int> left;
+    for (int d = 0; d < 3; d++)
+        for (int t = 0; t < NF; t++) left.push_back(d | t << 2);
+    int wt = 0, conflicts = 0;
+    std::vector<std::vector<bool>> used(7, std::vector<bool>(32, false));
+    std::vector<int> fill(7, 0);
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t k = 0; k < left.size();) {
+            const int d = left[k] & 3, t = left[k] >> 2;
+            const int r0 = pbase(d, t) & 31, r1 = (pbase(d, t) + pstride(d)) & 31;
+            bool placed = false;
+            for (int w = 0; w < 7 && !placed; w++) {
+                if (fill[w] >= 16) continue;
+                if (pass == 0 && (used[w][r0] || used[w][r1])) continue;
+                conflicts += (used[w][r0] || used[w][r1]) ? 1 : 0;
+                used[w][r0] = used[w][r1] = true;
+                tm[w * 16 + fill[w]++] = (short)left[k];
+                placed = true;
+            }
+            if (placed) left.erase(left.begin() + k);
+            else k++;
+        }
+    for (int w = 0; w < 7; w++) wt += fill[w] > 0;
+    if (!left.empty()) { fprintf(stderr, "pencils left over\n"); exit(1); }
+    fprintf(stderr, "form M: %d pencils placed with a bank conflict\n", conflicts);
+    fprintf(stderr, "form M: %d wave tasks for 108 pencils\n", wt);
+}
+
+int main(int argc, char** argv) {
+    const int steps = argc > 1 ? atoi(argv[1]) : 1000;     // Picard iterations (6 levels each)
+    std::mt19937_64 rng(6);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    double E[H * N], T[N * N];
+    for (double& x : E) x = U(rng);
+    for (double& x : T) x = 1e-3 * U(rng);
+    short tv[256], tm[128];
+    tables(tv, tm);
+    hipMemcpyToSymbol(HIP_SYMBOL(c_E), E, sizeof(E));
+    hipMemcpyToSymbol(HIP_SYMBOL(c_T), T, sizeof(T));
+    hipMemcpyToSymbol(HIP_SYMBOL(c_tabV), tv, sizeof(tv));
+    hipMemcpyToSymbol(HIP_SYMBOL(c_tabM), tm, sizeof(tm));
+    std::vector<double> q(NV * SL, 0.0);
+    for (int n = 0; n < NN; n++) {
+        const double v[5] = {1 + 0.2 * U(rng), 0.2 * U(rng), 0.2 * U(rng), 0.2 * U(rng), 2.6 + 0.3 * U(rng)};
+        for (int k = 0; k < 5; k++) q[k * SL + n] = v[k];
+    }
+    double *dq, *dout;
+    hipMalloc(&dq, q.size() * 8);
+    hipMalloc(&dout, 8 * 3 * NV * 2 * SL);
+    hipMemcpy(dq, q.data(), q.size() * 8, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto run = [&](auto kern, int cpw, size_t ldsb, int levels_per_step, const char* name) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kern, dim3(256), dim3(256 * cpw), ldsb, 0, dq, dout, steps, 6.0);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best = std::min(best, ms);
+        }
+        if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", name); return 0.0; }
+        const double cell_levels = (double)steps * N * cpw;                      // per CU (steps = Picard iterations of N levels)
+        (void)levels_per_step;
+        const double ns = 1e6 * best / cell_levels;
+        printf("%-46s %8.3f ms for %d iterations -> %7.1f ns = %6.0f cycles per (cell, level) and CU\n", name, best, steps, ns, ns * 2.4);
+        return ns;
+    };
+    const double v2 = run(probe<0, 2>, 2, sizeof(double) * 2 * Img<2>::CELL, 2, "V: 2 cells x 2 levels per step (shipped form)");
+    const double v1 = run(probe<0, 1>, 1, sizeof(double) * 1 * Img<2>::CELL, 2, "V: 1 cell alone");
+    const double m3 = run(probe<1, 3>, 3, sizeof(double) * 3 * Img<1>::CELL, 1, "M: 3 cells x 1 level per step, matrix derive");
+    const double m2 = run(probe<1, 2>, 2, sizeof(double) * 2 * Img<1>::CELL, 1, "M: 2 cells (same code, 2 waves per SIMD)");
+    const double m1 = run(probe<1, 1>, 1, sizeof(double) * 1 * Img<1>::CELL, 1, "M: 1 cell alone");
+    const double n3 = run(probe<2, 3>, 3, sizeof(double) * 3 * Img<1>::CELL, 1, "M': 3 cells, fold + load in one phase");
+    const double n2 = run(probe<2, 2>, 2, sizeof(double) * 2 * Img<1>::CELL, 1, "M': 2 cells");
+    printf("M'3 / V2 = %.3f   [M'2 %.0f ns]\n", n3 / v2, n2);
+    printf("M3 / V2 = %.3f  (below 0.92 would justify building the kernel: VERDICT r3 item 2)   [V1 %.0f, M2 %.0f, M1 %.0f ns]\n", m3 / v2, v1, m2, m1);
+    return 0;
+}
