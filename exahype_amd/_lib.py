@@ -33,6 +33,7 @@ SIGNATURES = {
     "exa_fv_grid_step_device": (C.c_int, [_vp, _vp, _vp, _lp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "exa_fv_max_eigenvalue": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp]),
     "exa_fv_time_step_device_masked": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, _vp]),
+    "exa_fv_time_step_device_masked_at": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "exa_dg_plan_create": (C.c_int, [C.c_int] * 6 + [_lp, C.POINTER(_vp)]),
     "exa_dg_plan_set_stage_a": (C.c_int, [_vp, C.c_int]),
     "exa_dg_stage_a_kernel": (C.c_char_p, [_vp]),

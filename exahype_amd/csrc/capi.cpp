@@ -211,6 +211,16 @@ int exa_fv_time_step_device_masked(exa_fv_plan* p, double* Q_dev, const long* sl
     return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, dt, h, slot_dev, (hipStream_t)stream);
 }
 
+int exa_fv_time_step_device_masked_at(exa_fv_plan* p, double* Q_dev, const long* slot_dev, const double* centre_dev, double t, double dt, double h,
+                                      void* stream) {
+    if (!p || (!Q_dev && p->count > 0)) { set_error("exa_fv_time_step_device_masked_at: NULL argument"); return EXA_ERR_INVALID; }
+    if (!(h > 0.0)) { set_error("exa_fv_time_step_device_masked_at needs the volume size h > 0 (volume centres, dt / h)"); return EXA_ERR_INVALID; }
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    return fv_launch(p->mode, p->dim, p->P, p->H, p->n_real, p->n_aux, p->n_patches, p->pde, Q_dev, dt, h, slot_dev, (hipStream_t)stream, nullptr,
+                     centre_dev, t);
+}
+
 int exa_fv_time_step_device_oop(exa_fv_plan* p, const double* QIn_dev, double* QOut_dev, const double* centre_dev, double t, double dt,
                                 double h, void* stream) {
     if (!p || ((!QIn_dev || !QOut_dev) && p->count > 0)) { set_error("exa_fv_time_step_device_oop: NULL argument"); return EXA_ERR_INVALID; }

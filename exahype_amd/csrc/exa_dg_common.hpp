@@ -80,6 +80,23 @@ template <int DIM, int N> struct Geo {
     }
 };
 
+// Where and when, for term sets whose terms depend on position / time (`Unit test/correctness_test.cpp:16-41`: flux / maxEigenvalue / sourceTerm
+// (Q, x, h, t, dt, ...)): node x = x0 + (cell + xi_i) h per axis, level time t_l = t + xi_l dt.  A kernel argument (scalar registers); the built-in
+// term sets never look at it.
+struct PlainGeo {
+    double x0[3];        // physical coordinates of the block's origin
+    double h[3];         // cell size
+    double t;            // time at the start of the step
+    double xi[MAXN];     // Gauss-Legendre nodes on [0, 1]
+};
+// xi[i] for a run-time i without indexing the argument dynamically (a select chain over scalar registers)
+template <int N> __device__ inline double xi_of(const PlainGeo& g, int i) {
+    double r = g.xi[0];
+#pragma unroll
+    for (int k = 1; k < N; k++) r = i == k ? g.xi[k] : r;
+    return r;
+}
+
 // what the one-kernel step (exa_dg_reg.hpp, FUSE) needs of the previous step
 struct RegFuse {
     const double* trace_in;       // traces of the previous step

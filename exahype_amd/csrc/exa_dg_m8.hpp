@@ -64,8 +64,13 @@ template <class PDE>
 __global__ void __launch_bounds__(512)
 dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out, double* __restrict__ trace,
                      long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
-                     const void* __restrict__ ops_raw, const void* __restrict__ step_raw, const int* __restrict__ tab) {
+                     const void* __restrict__ ops_raw, const void* __restrict__ step_raw, const int* __restrict__ tab, PlainGeo geo) {
     constexpr int N = 8, H = 4, DIM = 3;
+    // Term sets whose terms depend on position / time (XT) or carry a non-conservative product (NCP) -- generated term sets only (the hooks of
+    // `Unit test/correctness_test.cpp:16-41,145-155`), as in exa_dg_reg.hpp: coordinates and level times reach the flux and the source, the lane's
+    // two nodes get B_D(q) (D q) / h_D from two more matrix instructions per variable on q itself, the time-averaged ncp term is one more pass of
+    // the derive rounds over the final iterate.  Under `if constexpr`: the built-in term sets compile to the same code as before.
+    constexpr bool XT = pde_has_xt<PDE>::value, NCP = pde_has_ncp<PDE>::value;
     using G = M8Geo;
     using SA = StageAM8<PDE>;
     constexpr int NV = SA::NV, NA = SA::NA, NN = G::NN, NF = G::NF, SL = G::SL, VS = SA::VS, QSZ = SA::QSZ, AXO = SA::AXO, NT = SA::NT, LS = SA::LS;
@@ -94,6 +99,29 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         __syncthreads();
     }
     const int o_off = G::node_off(o_n);
+    [[maybe_unused]] double xc[3] = {0.0, 0.0, 0.0};                  // low corner of the current cell
+    [[maybe_unused]] double xio[3] = {0.0, 0.0, 0.0};                 // reference coordinates of the owner's node
+    if constexpr (XT) {
+        xio[0] = xi_of<N>(geo, o_n / NF);
+        xio[1] = xi_of<N>(geo, (o_n / N) % N);
+        xio[2] = xi_of<N>(geo, o_n % N);
+    }
+    [[maybe_unused]] auto owner_x = [&](double (&x)[3]) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) x[a] = xc[a] + xio[a] * geo.h[a];
+    };
+    [[maybe_unused]] auto level_t = [&](int l) -> double { return geo.t + geo.xi[l] * dt; };
+    [[maybe_unused]] auto source_at = [&](const double* qv, int l, double* S) {
+        if constexpr (pde_has_source<PDE>::value) {
+            if constexpr (XT) {
+                double x[3];
+                owner_x(x);
+                PDE::source_xt(qv, x, level_t(l), S);
+            } else {
+                PDE::source(qv, S);
+            }
+        }
+    };
 
     // derive role: node pair j = lane >> 4 of the pencil the lane tables give this lane (one per direction; the 16 pencils of a wave
     // have bank residues that keep the pairs k, k + 1 of a 32-lane group apart)
@@ -107,8 +135,10 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
     const double aEo = static_cast<const DgOps<N>*>(ops_raw)->DEO[d_j * N + H + (lane & 3)];
 
     // one round: direction D, results to A (D = 1), B (D = 2) or into hx (D = 0)
-    auto round = [&](auto dc, int tb, double (&hx)[2][NV]) {
+    // tA / tB: times of the two level slots (XT); mode 0: the derivative sums, 1: only their non-conservative part (the closing pass)
+    auto round = [&](auto dc, int tb, double (&hx)[2][NV], [[maybe_unused]] double tA, [[maybe_unused]] double tB, auto mode) {
         constexpr int D = decltype(dc)::value;
+        constexpr int MODE = decltype(mode)::value;
         const int off = ltab[(tb * 3 + D) * NT + opaque_v(tid)];
         if (off != 0xffff) {                                          // (wave-uniform: a wave has 16 pencils or none)
             constexpr int ps = G::pstride(D);
@@ -128,19 +158,66 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 ab[k] = EXA_SLD(AXO + nb + k * VS);
             }
             const double sc = D == 0 ? idx0 : (D == 1 ? idx1 : idx2);
-            PDE::template flux_scaled<D>(qa, aa, sc, Fa);
-            PDE::template flux_scaled<D>(qb, ab, sc, Fb);
+            // XT: positions of the lane's two nodes, time of its level slot (pencil (a, b) and level slot decoded from the table's offset)
+            [[maybe_unused]] double xa[3], xb[3], tl = 0.0;
+            if constexpr (XT) {
+                const int ls = off / SL, r = off - ls * SL;
+                const int a = D == 0 ? r / G::PY : r / G::PX, b = D == 0 ? r % G::PY : (D == 1 ? r % G::PX : (r % G::PX) / G::PY);
+                const double fa = xi_of<N>(geo, a), fb = xi_of<N>(geo, b), ja = xi_of<N>(geo, dj), jb = xi_of<N>(geo, N - 1 - dj);
+                xa[0] = xc[0] + (D == 0 ? ja : fa) * geo.h[0];
+                xa[1] = xc[1] + (D == 1 ? ja : (D == 0 ? fa : fb)) * geo.h[1];
+                xa[2] = xc[2] + (D == 2 ? ja : fb) * geo.h[2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) xb[c] = xa[c];
+                xb[D] = xc[D] + jb * geo.h[D];
+                tl = ls ? tB : tA;
+            }
+            if constexpr (MODE == 0) {
+                if constexpr (XT) {
+                    dg_flux_xt<PDE>(qa, xa, tl, D, Fa);
+                    dg_flux_xt<PDE>(qb, xb, tl, D, Fb);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) { Fa[v] *= sc; Fb[v] *= sc; }
+                } else {
+                    PDE::template flux_scaled<D>(qa, aa, sc, Fa);
+                    PDE::template flux_scaled<D>(qb, ab, sc, Fb);
+                }
+            }
+            [[maybe_unused]] double na_[NV], nb_[NV];                   // B_D(q) (D q) / h_D at the lane's two nodes
+            if constexpr (NCP) {
+                double ga[NV], gb[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const double Pq = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, qa[v] + qb[v], 0.0, 0, 0, 0);
+                    const double Mq = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, qa[v] - qb[v], 0.0, 0, 0, 0);
+                    ga[v] = sc * (Mq + Pq);
+                    gb[v] = sc * (Mq - Pq);
+                    na_[v] = 0.0;
+                    nb_[v] = 0.0;
+                }
+                dg_ncp<PDE>(qa, ga, xa, tl, D, na_);
+                dg_ncp<PDE>(qb, gb, xb, tl, D, nb_);
+            }
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
-                const double Pv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, e, 0.0, 0, 0, 0);
-                const double Mv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, o, 0.0, 0, 0, 0);
+                double sa = 0.0, sb = 0.0;
+                if constexpr (MODE == 0) {
+                    const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
+                    const double Pv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, e, 0.0, 0, 0, 0);
+                    const double Mv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, o, 0.0, 0, 0, 0);
+                    sa = Mv + Pv;
+                    sb = Mv - Pv;
+                }
+                if constexpr (NCP) {
+                    sa += na_[v];
+                    sb += nb_[v];
+                }
                 if constexpr (D == 0) {
-                    hx[0][v] = Mv + Pv;
-                    hx[1][v] = Mv - Pv;
+                    hx[0][v] = sa;
+                    hx[1][v] = sb;
                 } else {
-                    lds[D * QSZ + na + v * VS] = Mv + Pv;
-                    lds[D * QSZ + nb + v * VS] = Mv - Pv;
+                    lds[D * QSZ + na + v * VS] = sa;
+                    lds[D * QSZ + nb + v * VS] = sb;
                 }
             }
         }
@@ -148,9 +225,12 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 #ifndef EXA_M8_PIPE          // (measured SLOWER: 117.3 against 98.2 ms per 64^3 launch -- the 28 VGPRs of the next round's operands do not exist: 204 B of scratch)
 #define EXA_M8_PIPE 0
 #endif
-    auto derive = [&](int tb) {                                       // tb: 0 = steps of two levels, 1 = iteration 0 (one level)
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    auto derive = [&](int tb, double tA, double tB, auto mode) {      // tb: 0 = steps of two levels, 1 = iteration 0 (one level)
         double hx[2][NV];
 #if EXA_M8_PIPE
+        static_assert(!XT && !NCP, "EXA_M8_PIPE: built-in term sets only");
         // software-pipelined over the three rounds: the LDS loads of the next round are issued in front of the matrix instructions and the
         // stores of the current one (they read Q and the scalars, which no round writes), so their latency and the store queue overlap
         const int t_ = opaque_v(tid), dj = opaque_v(d_j);
@@ -221,9 +301,9 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         evenodd(D0{}, r, e, o);
         matrix(D0{}, true, 0, 0, e, o);                               // x last: its sums wait in registers for the barrier
 #else
-        round(std::integral_constant<int, 1>{}, tb, hx);
-        round(std::integral_constant<int, 2>{}, tb, hx);
-        round(std::integral_constant<int, 0>{}, tb, hx);             // x last: its sums wait in registers for the barrier
+        round(std::integral_constant<int, 1>{}, tb, hx, tA, tB, mode);
+        round(std::integral_constant<int, 2>{}, tb, hx, tA, tB, mode);
+        round(std::integral_constant<int, 0>{}, tb, hx, tA, tB, mode);      // x last: its sums wait in registers for the barrier
 #endif
         __syncthreads();                                              // every read of Q is done; S_y (A), S_z (B) are complete
         const int off = ltab[(tb * 3 + 0) * NT + opaque_v(tid)];
@@ -249,54 +329,65 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 
     for (long b = blockIdx.x; b < box.nbox; b += gridDim.x) {
         const long cell = box.cell(b);
+        if constexpr (XT) {
+            const long cz = b % box.nb[2], cy = (b / box.nb[2]) % box.nb[1], cx = b / (box.nb[2] * box.nb[1]);
+            xc[0] = geo.x0[0] + (double)(box.lo[0] + cx) * geo.h[0];
+            xc[1] = geo.x0[1] + (double)(box.lo[1] + cy) * geo.h[1];
+            xc[2] = geo.x0[2] + (double)(box.lo[2] + cz) * geo.h[2];
+        }
         const double* up = u_in + (cell * NN + o_n) * NV;             // (u is re-read where needed: an L2 hit against 10 VGPRs of a kernel at its cap)
         double u[NV], q[N][NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) u[v] = up[v];
 
-        // ---- Picard iteration 0: the iterate is constant in time -- one level, row sums of T
-        put_level(0, u);
-        EXA_STAMP(0);
-        __syncthreads();
-        EXA_STAMP(1);
-        {
-            derive(1);                                               // iteration 0 has its own table (one level: four waves per round)
-        }
-        EXA_STAMP(2);
-        {
-            double S[NV], Ts[N];
-            sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                const int p = o_off + v * VS;
-                const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
-                S[v] = sx + (sy + sz);
-            }
-            if constexpr (pde_has_source<PDE>::value) {
-                double Sq[NV];
-                PDE::source(u, Sq);
-#pragma unroll
-                for (int v = 0; v < NV; v++) S[v] -= Sq[v];
-            }
+        // (XT: the terms depend on the level time -- every iteration is a full one, started from q_l = u)
+        if constexpr (XT) {
 #pragma unroll
             for (int l = 0; l < N; l++)
 #pragma unroll
-                for (int v = 0; v < NV; v++) q[l][v] = fma(Ts[l], S[v], u[v]);
-        }
-        EXA_STAMP(3);
+                for (int v = 0; v < NV; v++) q[l][v] = u[v];
+        } else {
+            // ---- Picard iteration 0: the iterate is constant in time -- one level, row sums of T
+            put_level(0, u);
+            EXA_STAMP(0);
+            __syncthreads();
+            EXA_STAMP(1);
+            {
+                derive(1, 0.0, 0.0, M0{});                               // iteration 0 has its own table (one level: four waves per round)
+            }
+            EXA_STAMP(2);
+            {
+                double S[NV], Ts[N];
+                sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
+    #pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const int p = o_off + v * VS;
+                    const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
+                    S[v] = sx + (sy + sz);
+                }
+                if constexpr (pde_has_source<PDE>::value) {
+                    double Sq[NV];
+                    source_at(u, 0, Sq);
+    #pragma unroll
+                    for (int v = 0; v < NV; v++) S[v] -= Sq[v];
+                }
+    #pragma unroll
+                for (int l = 0; l < N; l++)
+    #pragma unroll
+                    for (int v = 0; v < NV; v++) q[l][v] = fma(Ts[l], S[v], u[v]);
+            }
+            EXA_STAMP(3);
 
+        }
         // ---- Picard iterations 1 .. n_it - 1: steps of two levels; the load of the next step's levels sits inside the fold
-        [[maybe_unused]] double Sq[2][NV], Sqn[2][NV];
-        auto load_levels = [&](auto lc, const double (&qq)[N][NV], double (&S2)[2][NV]) {
+        auto load_levels = [&](auto lc, const double (&qq)[N][NV]) {
             constexpr int l0 = decltype(lc)::value;
 #pragma unroll
-            for (int ls = 0; ls < 2; ls++) {
-                put_level(ls, qq[l0 + ls]);
-                if constexpr (pde_has_source<PDE>::value) PDE::source(qq[l0 + ls], S2[ls]);
-            }
+            for (int ls = 0; ls < 2; ls++) put_level(ls, qq[l0 + ls]);
         };
-        if (n_it > 1) load_levels(std::integral_constant<int, 0>{}, q, Sq);
-        for (int it = 1; it < n_it; it++) {
+        constexpr int IT0 = XT ? 0 : 1;                                // first full iteration
+        if (n_it > IT0) load_levels(std::integral_constant<int, 0>{}, q);
+        for (int it = IT0; it < n_it; it++) {
             double acc[N][NV];
             static_for<0, LS>([&](auto sc_) {
                 constexpr int st = decltype(sc_)::value;
@@ -311,7 +402,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                     for (int v = 0; v < NV; v++) uu[v] = up[v];
                 }
 #endif
-                derive(0);
+                derive(0, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M0{});
                 EXA_STAMP(6);
                 double Tm[2 * N];                                      // -dt T[l'][l0 + ls], l' fastest
                 sload<2 * N>(step_here<N>(step_raw)->TdtT + l0 * N, Tm);
@@ -330,9 +421,17 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                         const int p = o_off + ls * SL + v * VS;
                         const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
                         Sx[ls][v] = sx + (sy + sz);
-                        if constexpr (pde_has_source<PDE>::value) Sx[ls][v] -= Sq[ls][v];
                     }
-                if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q, Sqn);
+                if constexpr (pde_has_source<PDE>::value) {           // q_t + div F = S(q): on the iterate in the owner's registers
+#pragma unroll
+                    for (int ls = 0; ls < 2; ls++) {
+                        double Sq[NV];
+                        source_at(q[l0 + ls], l0 + ls, Sq);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) Sx[ls][v] -= Sq[v];
+                    }
+                }
+                if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q);
 #pragma unroll
                 for (int ls = 0; ls < 2; ls++)
 #pragma unroll
@@ -342,14 +441,8 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                             if constexpr (st == 0) acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], ls == 0 ? uu[v] : acc[lp][v]);
                             else acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], acc[lp][v]);
                         }
-                if constexpr (pde_has_source<PDE>::value) {
-#pragma unroll
-                    for (int ls = 0; ls < 2; ls++)
-#pragma unroll
-                        for (int v = 0; v < NV; v++) Sq[ls][v] = Sqn[ls][v];
-                }
                 if constexpr (st + 1 == LS) {
-                    if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, acc, Sq);
+                    if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, acc);
                 }
                 EXA_STAMP(7);
             });
@@ -359,6 +452,31 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 for (int v = 0; v < NV; v++) q[l][v] = acc[l][v];
         }
 
+        // ---- NCP: the time-averaged non-conservative term of the FINAL iterate enters u* point-wise: one more pass of the derive rounds over the
+        // levels, non-conservative part only, weighted with w_l by the owners
+        [[maybe_unused]] double pw[NV];
+        if constexpr (NCP) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) pw[v] = 0.0;
+            load_levels(std::integral_constant<int, 0>{}, q);
+            static_for<0, LS>([&](auto sc_) {
+                constexpr int st = decltype(sc_)::value;
+                constexpr int l0 = 2 * st;
+                __syncthreads();
+                derive(0, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M1{});
+                double wl[2];
+                sload<2>(ops_here<N>(ops_raw)->w + l0, wl);
+#pragma unroll
+                for (int ls = 0; ls < 2; ls++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        const int p = o_off + ls * SL + v * VS;
+                        const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
+                        pw[v] = fma(wl[ls], sx + (sy + sz), pw[v]);
+                    }
+                if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q);
+            });
+        }
         // ---- time averages: qbar | Fbar_x | Fbar_y | Fbar_z (| time-averaged source)
         __syncthreads();                                              // every fold has read its sums: the closing image reuses the LDS
         {
@@ -384,13 +502,19 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[l][v];
                 static_for<0, DIM>([&](auto dc) {
                     constexpr int D = decltype(dc)::value;
-                    PDE::template flux<D>(q[l], a, F);
+                    if constexpr (XT) {
+                        double xo[3];
+                        owner_x(xo);
+                        dg_flux_xt<PDE>(q[l], xo, level_t(l), D, F);
+                    } else {
+                        PDE::template flux<D>(q[l], a, F);
+                    }
 #pragma unroll
                     for (int v = 0; v < NV; v++) Fb[D][v] += wm[l] * F[v];
                 });
                 if constexpr (pde_has_source<PDE>::value) {
                     double S1[NV];
-                    PDE::source(q[l], S1);
+                    source_at(q[l], l, S1);
 #pragma unroll
                     for (int v = 0; v < NV; v++) Sbar[v] += wm[l] * S1[v];
                 }
@@ -451,6 +575,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 double us = up[v];
+                if constexpr (NCP) us -= dt * pw[v];
                 if constexpr (pde_has_source<PDE>::value) us += dt * EXA_SLD((4 * NV + v) * SL + o_off);
 #pragma unroll
                 for (int d = 0; d < DIM; d++) us += EXA_SLD(((1 + d) * NV + v) * SL + o_off);

@@ -19,13 +19,6 @@
 
 namespace exa {
 
-struct PlainGeo {
-    double x0[3];        // physical coordinates of the block's origin
-    double h[3];         // cell size
-    double t;            // time at the start of the step
-    double xi[MAXN];     // Gauss-Legendre nodes on [0, 1]
-};
-
 template <int DIM, int N, class PDE> struct StagePlain {
     static constexpr int NV = PDE::NV;
     static constexpr int NN = ipow(N, DIM), NF = ipow(N, DIM - 1);

@@ -128,7 +128,13 @@ template <int N, class PDE, int CPW, bool FUSE = false>
 __global__ void __launch_bounds__(256 * CPW, 2)
 dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ trace,
                       long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
-                      const void* __restrict__ ops_raw, const int* __restrict__ tab, const void* __restrict__ step_raw, RegFuse fz) {
+                      const void* __restrict__ ops_raw, const int* __restrict__ tab, const void* __restrict__ step_raw, RegFuse fz, PlainGeo geo) {
+    // Term sets whose terms depend on position / time (XT) or carry a non-conservative product (NCP) -- generated term sets only
+    // (pde_codegen.SympyPDE; the hooks of `Unit test/correctness_test.cpp:16-41,145-155`): node coordinates and level times reach the flux and
+    // the source, B_d(q) (D q)_i / h_d joins the derivative sums of the pencil's nodes, the time-averaged ncp term is one more pass of the
+    // derive phase over the final iterate.  Everything under `if constexpr`: the built-in term sets compile to the same code as before.
+    constexpr bool XT = pde_has_xt<PDE>::value, NCP = pde_has_ncp<PDE>::value;
+    static_assert(!(FUSE && (XT || NCP)), "the one-kernel step is built for term sets without coordinates / ncp");
     using G = RegGeo<N>;
     using SA = StageAReg<N, PDE, CPW>;
     constexpr int NV = SA::NV, NA = SA::NA, DIM = 3;
@@ -195,6 +201,8 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     struct Task {                                                      // one pencil task, decoded: first node, node stride (elements), array group of its sums
         int off, ps, so;
         bool on;
+        int d, ls;                                                     // (XT / NCP: direction and level slot)
+        double xa, xb;                                                 // (XT: reference coordinates xi of the pencil's two fixed node indices, axes ascending)
     };
     auto decode = [&](int pk, Task& k, DirFlux<PDE>& fx) {
         const int d = pk & 3, ls = (pk >> 2) & 1, t = pk >> 3;
@@ -203,7 +211,44 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         k.off = ls * SL + (d == 0 ? a * PY + b : (d == 1 ? a * PX + b : a * PX + b * PY));
         k.ps = d == 0 ? PX : (d == 1 ? PY : 1);
         k.so = SOFF + d * QSZ;                                         // array group of this direction's sums
+        k.d = d;
+        k.ls = ls;
+        if constexpr (XT) {
+            k.xa = xi_of<N>(geo, a);
+            k.xb = xi_of<N>(geo, b);
+        }
         fx = DirFlux<PDE>(d, d == 0 ? idx0 : (d == 1 ? idx1 : idx2));
+    };
+    // XT: position of node jn of a pencil in the cell whose low corner is xc; time of the task's level slot
+    [[maybe_unused]] double xc[3] = {0.0, 0.0, 0.0};                  // low corner of the current cell (wave-uniform)
+    [[maybe_unused]] auto pencil_x = [&](const Task& tk, int d, int jn, double (&x)[3]) {
+        const double xj = geo.xi[jn];
+        x[0] = xc[0] + (d == 0 ? xj : tk.xa) * geo.h[0];
+        x[1] = xc[1] + (d == 1 ? xj : (d == 0 ? tk.xa : tk.xb)) * geo.h[1];
+        x[2] = xc[2] + (d == 2 ? xj : tk.xb) * geo.h[2];
+    };
+    // owner lane: reference coordinates of its node (once per kernel), position in the current cell
+    [[maybe_unused]] double xio[3] = {0.0, 0.0, 0.0};
+    if constexpr (XT) {
+        xio[0] = xi_of<N>(geo, o_n / (N * N));
+        xio[1] = xi_of<N>(geo, (o_n / N) % N);
+        xio[2] = xi_of<N>(geo, o_n % N);
+    }
+    [[maybe_unused]] auto owner_x = [&](double (&x)[3]) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) x[a] = xc[a] + xio[a] * geo.h[a];
+    };
+    [[maybe_unused]] auto level_t = [&](int l) -> double { return geo.t + geo.xi[l] * dt; };     // (l: compile-time at every call)
+    [[maybe_unused]] auto source_at = [&](const double* qv, int l, double* S) {
+        if constexpr (pde_has_source<PDE>::value) {
+            if constexpr (XT) {
+                double x[3];
+                owner_x(x);
+                PDE::source_xt(qv, x, level_t(l), S);
+            } else {
+                PDE::source(qv, S);
+            }
+        }
     };
     // the task of the two-level steps stays decoded in registers (30 integer instructions per step otherwise, 12 % of the phase)
     Task tk2;
@@ -213,7 +258,12 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     // first half: every node of the pencil is requested at once; flux at the nodes; the even / odd combinations e_j = F_j + F_{N-1-j},
     // o_j = F_j - F_{N-1-j} stay in registers
     static_assert(N % 2 == 0, "register-resident stage A: even N (the middle node of an odd N is not coded)");
-    auto derive_a = [&](const Task& tk, const DirFlux<PDE>& fx, double (&e)[H][NV], double (&o)[H][NV]) {
+    // tA / tB: times of the two level slots of the step (XT).  MODE 0: the derivative sums; 1: only the non-conservative part (the closing pass)
+    // dc: the task's direction as a compile-time value (term sets whose flux has no per-lane-normal form: the caller splits by direction once
+    // per task, so that the term calls see a constant normal), or -1: run-time normal through the masks of DirFlux
+    auto derive_a = [&](auto dc, const Task& tk, const DirFlux<PDE>& fx, double (&e)[H][NV], double (&o)[H][NV], [[maybe_unused]] double tA,
+                        [[maybe_unused]] double tB) {
+        constexpr int DC = decltype(dc)::value;
         if (tk.on && active_now) {
             const int off = tk.off, ps = tk.ps;
             double qa[N][NVA];                                         // q | flux scalars of the six nodes
@@ -222,15 +272,85 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 ld_group(0, off + j * ps, qa[j]);
                 ld_group(0, off + (N - 1 - j) * ps, qa[N - 1 - j]);
             }
+            [[maybe_unused]] const double tl = tk.ls ? tB : tA;
+            [[maybe_unused]] const int dd = DC >= 0 ? DC : tk.d;
+            [[maybe_unused]] const double scd = dd == 0 ? idx0 : (dd == 1 ? idx1 : idx2);
 #pragma unroll
             for (int j = 0; j < H; j++) {
                 double Fa[NV], Fb[NV];
-                fx(qa[j], qa[j] + NV, Fa);
-                fx(qa[N - 1 - j], qa[N - 1 - j] + NV, Fb);
+                if constexpr (XT) {
+                    double xj[3];
+                    pencil_x(tk, dd, j, xj);
+                    dg_flux_xt<PDE>(qa[j], xj, tl, dd, Fa);
+                    pencil_x(tk, dd, N - 1 - j, xj);
+                    dg_flux_xt<PDE>(qa[N - 1 - j], xj, tl, dd, Fb);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) { Fa[v] *= scd; Fb[v] *= scd; }
+                } else if constexpr (DC >= 0) {
+                    PDE::template flux_scaled<DC>(qa[j], qa[j] + NV, scd, Fa);
+                    PDE::template flux_scaled<DC>(qa[N - 1 - j], qa[N - 1 - j] + NV, scd, Fb);
+                } else {
+                    fx(qa[j], qa[j] + NV, Fa);
+                    fx(qa[N - 1 - j], qa[N - 1 - j] + NV, Fb);
+                }
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     e[j][v] = Fa[v] + Fb[v];
                     o[j][v] = Fa[v] - Fb[v];
+                }
+            }
+        }
+    };
+    // NCP: B_d(q_i) (D q)_i / h_d at the nodes of the pencil, row pair by row pair (even-odd form of D on q itself: the combinations
+    // q_j +- q_{N-1-j} are formed on the fly), stored where this direction's sums go -- derive_b adds its sums to them.  A pass of its own in front
+    // of the flux part, with its own loads of q (no flux scalars): the six states of the pencil are live here and only here.
+    [[maybe_unused]] auto derive_n = [&](auto dc, const Task& tk, [[maybe_unused]] const double (&Em)[NE], [[maybe_unused]] double tA, [[maybe_unused]] double tB) {
+        constexpr int DC = decltype(dc)::value;
+        if constexpr (NCP) {
+            // (run-time direction here, DC = -1: with this part inside the per-direction branches the back-end of ROCm 7.2 stops with "illegal VGPR
+            // to SGPR copy" on the SGPR-pinned operator entries; the generated ncp members switch on the direction themselves)
+            const int dn = DC >= 0 ? DC : tk.d;
+            if (tk.on && active_now) {
+                const int off = tk.off, ps = tk.ps;
+                [[maybe_unused]] const double tl = tk.ls ? tB : tA;
+                double qa[N][NV];
+#pragma unroll
+                for (int j = 0; j < N; j++) ld_group(0, off + j * ps, qa[j]);
+                const double scd = dn == 0 ? idx0 : (dn == 1 ? idx1 : idx2);
+#pragma unroll
+                for (int i = 0; i < H; i++) {
+                    double Mq[NV], Pq[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; v++) { Mq[v] = 0.0; Pq[v] = 0.0; }
+#pragma unroll
+                    for (int j = 0; j < H; j++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) {
+                            Mq[v] = fma(Em[j * N + H + i], qa[j][v] - qa[N - 1 - j][v], Mq[v]);
+                            Pq[v] = fma(Em[j * N + i], qa[j][v] + qa[N - 1 - j][v], Pq[v]);
+                        }
+                    double gI[NV], gM[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; v++) { gI[v] = scd * (Mq[v] + Pq[v]); gM[v] = scd * (Mq[v] - Pq[v]); }
+                    // one node at a time, each result stored before the next starts (the kernel is at its register cap: the scheduler must not
+                    // interleave the row pairs)
+                    double xj[3] = {0.0, 0.0, 0.0};
+                    {
+                        double nI[NV];
+#pragma unroll
+                        for (int v = 0; v < NV; v++) nI[v] = 0.0;
+                        if constexpr (XT) pencil_x(tk, dn, i, xj);
+                        dg_ncp<PDE>(qa[i], gI, xj, tl, dn, nI);
+                        st_group(tk.so, off + i * ps, nI);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double nM[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; v++) nM[v] = 0.0;
+                    if constexpr (XT) pencil_x(tk, dn, N - 1 - i, xj);
+                    dg_ncp<PDE>(qa[N - 1 - i], gM, xj, tl, dn, nM);
+                    st_group(tk.so, off + (N - 1 - i) * ps, nM);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -260,6 +380,13 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 double sM[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) sM[v] = fma(2.0, M[v], -sI[v]);
+                if constexpr (NCP) {                                   // + the non-conservative part derive_a left there (same lane, same entries)
+                    double nI[NV], nM[NV];
+                    ld_group(so, off + i * ps, nI);
+                    ld_group(so, off + (N - 1 - i) * ps, nM);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) { sI[v] += nI[v]; sM[v] += nM[v]; }
+                }
                 st_group(so, off + i * ps, sI);
                 st_group(so, off + (N - 1 - i) * ps, sM);
             }
@@ -268,16 +395,35 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     // (-DEXA_REG_SPLIT, CPW == 2: a barrier between the halves, i.e. three segments of similar length per step, the second cell in flight one
     //  segment behind the first -- measured 9 % SLOWER than two segments: a barrier costs more than the better balance returns,
     //  profiles/r03_reg_kernel.txt)
-    auto derive = [&](const Task& tk, const DirFlux<PDE>& fx, const double (&Em)[NE]) {
-        double e[H][NV], o[H][NV];
+    using M0 = std::integral_constant<int, 0>;                       // derive: the derivative sums
+    using M1 = std::integral_constant<int, 1>;                       // ... only their non-conservative part
+    // (ncp term sets keep the run-time direction: at their register pressure the three copies of the flux part measured slower, 34.6 against 26.1 ms
+    //  per 32^3 launch of Euler with its pressure gradient as an ncp)
+    constexpr bool SPLIT_DIR = !NCP && (XT || !pde_has_dir<PDE>::value);
+    auto derive = [&](const Task& tk, const DirFlux<PDE>& fx, const double (&Em)[NE], double tA, double tB, auto mode) {
         // the derive stream is the long one of a step: it gets the SIMD's issue slots ahead of the co-resident wave of the other cell in
         // flight (in its fold / load / closing segment) -- 8 % of the launch (profiles/r03_reg_kernel.txt)
         __builtin_amdgcn_s_setprio(EXA_REG_PRIO);
-        derive_a(tk, fx, e, o);
+        double e[H][NV], o[H][NV];
+        derive_n(std::integral_constant<int, -1>{}, tk, Em, tA, tB);
+        auto front = [&](auto dc) {                                    // the direction-dependent part: term calls
+            if constexpr (decltype(mode)::value == 0) derive_a(dc, tk, fx, e, o, tA, tB);
+        };
+        if constexpr (SPLIT_DIR) {
+            // no per-lane-normal form of the flux (DirFlux<PDE, true>): the lanes of a wave take the branch of their direction, the term
+            // calls inside see a compile-time normal (a wave with pencils of two directions runs two branches)
+            if (tk.d == 0) front(std::integral_constant<int, 0>{});
+            else if (tk.d == 1) front(std::integral_constant<int, 1>{});
+            else front(std::integral_constant<int, 2>{});
+        } else {
+            front(std::integral_constant<int, -1>{});
+        }
+        if constexpr (decltype(mode)::value == 0) {
 #ifdef EXA_REG_SPLIT
-        if constexpr (CPW == 2) bar();
+            if constexpr (CPW == 2) bar();
 #endif
-        derive_b(tk, Em, e, o);
+            derive_b(tk, Em, e, o);                                    // the contraction is the same for every direction
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -379,6 +525,11 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         active_now = active;
         const bool owner = node_lane && active;
         const long cell = active ? cell_of(cx, cy, cz) : 0;
+        if constexpr (XT) {
+            xc[0] = geo.x0[0] + (double)(box.lo[0] + cx) * geo.h[0];
+            xc[1] = geo.x0[1] + (double)(box.lo[1] + cy) * geo.h[1];
+            xc[2] = geo.x0[2] + (double)(box.lo[2] + cz) * geo.h[2];
+        }
         cz += sz;
         if (cz >= nb2) { cz -= nb2; cy += 1; }
         cy += sy;
@@ -462,63 +613,69 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 for (int v = 0; v < NV; v++) uo[v] = upend[v];
             }
         }
-        if (owner) put_level(0, un);
-        EXA_STAMP(0);
-        bar();
-        EXA_STAMP(1);
-        {
-            Task tk1;
-            DirFlux<PDE> fx1(0, 0.0);
-            decode(opaque_v(pk1), tk1, fx1);
-            derive(tk1, fx1, Em);
-        }
-        EXA_STAMP(2);
-        bar();
-        EXA_STAMP(3);
-        if (owner) {
-            double S[NV], Ts[N];
-            sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
-            {
-                double Sx[NV], Sy[NV], Sz[NV];
-                ld_group(SOFF, o_n, Sx);
-                ld_group(SOFF + QSZ, o_n, Sy);
-                ld_group(SOFF + 2 * QSZ, o_n, Sz);
-#pragma unroll
-                for (int v = 0; v < NV; v++) S[v] = Sx[v] + (Sy[v] + Sz[v]);
-            }
-            if constexpr (pde_has_source<PDE>::value) {                // q_t + div F = S(q)
-                double Sq[NV];
-                PDE::source(un, Sq);
-#pragma unroll
-                for (int v = 0; v < NV; v++) S[v] -= Sq[v];
-            }
+        // (XT: the terms depend on the level time, so a constant iterate does not make the levels equal -- every iteration is a full one, started
+        // from q_l = u as the scheme defines it)
+        if constexpr (XT) {
 #pragma unroll
             for (int l = 0; l < N; l++)
 #pragma unroll
-                for (int v = 0; v < NV; v++) q[l][v] = fma(Ts[l], S[v], un[v]);
+                for (int v = 0; v < NV; v++) q[l][v] = owner ? un[v] : 1.0;
         } else {
-#pragma unroll
-            for (int l = 0; l < N; l++)
-#pragma unroll
-                for (int v = 0; v < NV; v++) q[l][v] = 1.0;
-        }
-        EXA_STAMP(4);
+            if (owner) put_level(0, un);
+            EXA_STAMP(0);
+            bar();
+            EXA_STAMP(1);
+            {
+                Task tk1;
+                DirFlux<PDE> fx1(0, 0.0);
+                decode(opaque_v(pk1), tk1, fx1);
+                derive(tk1, fx1, Em, 0.0, 0.0, M0{});
+            }
+            EXA_STAMP(2);
+            bar();
+            EXA_STAMP(3);
+            if (owner) {
+                double S[NV], Ts[N];
+                sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
+                {
+                    double Sx[NV], Sy[NV], Sz[NV];
+                    ld_group(SOFF, o_n, Sx);
+                    ld_group(SOFF + QSZ, o_n, Sy);
+                    ld_group(SOFF + 2 * QSZ, o_n, Sz);
+    #pragma unroll
+                    for (int v = 0; v < NV; v++) S[v] = Sx[v] + (Sy[v] + Sz[v]);
+                }
+                if constexpr (pde_has_source<PDE>::value) {                // q_t + div F = S(q)
+                    double Sq[NV];
+                    PDE::source(un, Sq);
+    #pragma unroll
+                    for (int v = 0; v < NV; v++) S[v] -= Sq[v];
+                }
+    #pragma unroll
+                for (int l = 0; l < N; l++)
+    #pragma unroll
+                    for (int v = 0; v < NV; v++) q[l][v] = fma(Ts[l], S[v], un[v]);
+            } else {
+    #pragma unroll
+                for (int l = 0; l < N; l++)
+    #pragma unroll
+                    for (int v = 0; v < NV; v++) q[l][v] = 1.0;
+            }
+            EXA_STAMP(4);
 
+        }
         // ---- Picard iterations 1 .. n_it - 1.  A step = [load] barrier [derive] barrier [fold]; the load of the NEXT step is issued inside the
         // fold, between its LDS loads and its arithmetic (the levels it writes are in registers since the previous iteration, and an owner
         // rewrites only its own node, which nobody reads between these two barriers): the 14 stores per lane drain under the fold's FMAs.
-        auto load_levels = [&](auto lc, const double (&qq)[N][NV], double (&Sq)[2][NV]) {
+        auto load_levels = [&](auto lc, const double (&qq)[N][NV]) {
             constexpr int l0 = decltype(lc)::value;
             constexpr int NL = (l0 + 1 < N) ? 2 : 1;
 #pragma unroll
-            for (int ls = 0; ls < NL; ls++) {
-                put_level(ls, qq[l0 + ls]);
-                if constexpr (pde_has_source<PDE>::value) PDE::source(qq[l0 + ls], Sq[ls]);
-            }
+            for (int ls = 0; ls < NL; ls++) put_level(ls, qq[l0 + ls]);
         };
-        [[maybe_unused]] double Sq[2][NV], Sqn[2][NV];                 // source terms of the levels in LDS | of the levels just loaded
-        if (n_it > 1 && owner) load_levels(std::integral_constant<int, 0>{}, q, Sq);
-        for (int it = 1; it < n_it; it++) {
+        constexpr int IT0 = XT ? 0 : 1;                                // first full iteration
+        if (n_it > IT0 && owner) load_levels(std::integral_constant<int, 0>{}, q);
+        for (int it = IT0; it < n_it; it++) {
             double acc[N][NV];
             static_for<0, LS>([&](auto sc_) {
                 constexpr int st = decltype(sc_)::value;
@@ -529,7 +686,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 bar();
                 EXA_STAMP(6);
                 static_assert(NL == 2, "odd N: the last step of an iteration has one level -- mask the tasks of level slot 1");
-                derive(tk2, fx2, Em);
+                derive(tk2, fx2, Em, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M0{});
                 // what the fold needs from memory, requested in front of the barrier: -dt T[l'][l0 + ls] (l' fastest) and, where the
                 // iteration starts its accumulators, u
                 double Tm[NL * N], uu[NV];
@@ -551,15 +708,22 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                         ld_group(SOFF + QSZ, o_n + ls * SL, Sy[ls]);
                         ld_group(SOFF + 2 * QSZ, o_n + ls * SL, Sz[ls]);
                     }
-                    if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q, Sqn);     // the next step's levels
+                    if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q);     // the next step's levels
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ls = 0; ls < NL; ls++)
 #pragma unroll
-                        for (int v = 0; v < NV; v++) {
-                            Sx[ls][v] += Sy[ls][v] + Sz[ls][v];
-                            if constexpr (pde_has_source<PDE>::value) Sx[ls][v] -= Sq[ls][v];
+                        for (int v = 0; v < NV; v++) Sx[ls][v] += Sy[ls][v] + Sz[ls][v];
+                    if constexpr (pde_has_source<PDE>::value) {        // q_t + div F = S(q): evaluated here, on the iterate in the owner's registers
+                        // (kept from the load to the fold, the sources of two steps cost 40 VGPRs of a kernel at its cap)
+#pragma unroll
+                        for (int ls = 0; ls < NL; ls++) {
+                            double Sq[NV];
+                            source_at(q[l0 + ls], l0 + ls, Sq);
+#pragma unroll
+                            for (int v = 0; v < NV; v++) Sx[ls][v] -= Sq[v];
                         }
+                    }
 #pragma unroll
                     for (int ls = 0; ls < NL; ls++)
 #pragma unroll
@@ -569,15 +733,9 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                                 if constexpr (st == 0) acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], ls == 0 ? uu[v] : acc[lp][v]);
                                 else acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], acc[lp][v]);
                             }
-                    if constexpr (pde_has_source<PDE>::value) {
-#pragma unroll
-                        for (int ls = 0; ls < 2; ls++)
-#pragma unroll
-                            for (int v = 0; v < NV; v++) Sq[ls][v] = Sqn[ls][v];
-                    }
                     // the last step of an iteration completes the new iterate: its first levels go to LDS right away
                     if constexpr (st + 1 == LS) {
-                        if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, acc, Sq);
+                        if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, acc);
                     }
                 }
                 EXA_STAMP(9);
@@ -588,6 +746,36 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 for (int v = 0; v < NV; v++) q[l][v] = owner ? acc[l][v] : 1.0;
         }
 
+        // ---- NCP: the time-averaged non-conservative term  sum_l w_l sum_d B_d(q_l) (D q_l) / h_d  of the FINAL iterate enters u* point-wise: one more
+        // pass of the derive phase over the levels, non-conservative part only, the owners weight what arrives with w_l
+        [[maybe_unused]] double pw[NV];
+        if constexpr (NCP) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) pw[v] = 0.0;
+            if (owner) load_levels(std::integral_constant<int, 0>{}, q);
+            static_for<0, LS>([&](auto sc_) {
+                constexpr int st = decltype(sc_)::value;
+                constexpr int l0 = st * 2;
+                sload<NE>(ops_here<N>(ops_raw)->DEO, Em);
+                bar();
+                derive(tk2, fx2, Em, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M1{});
+                bar();
+                if (owner) {
+                    double wl[2];
+                    sload<2>(ops_here<N>(ops_raw)->w + l0, wl);
+#pragma unroll
+                    for (int ls = 0; ls < 2; ls++) {
+                        double Sx[NV], Sy[NV], Sz[NV];
+                        ld_group(SOFF, o_n + ls * SL, Sx);
+                        ld_group(SOFF + QSZ, o_n + ls * SL, Sy);
+                        ld_group(SOFF + 2 * QSZ, o_n + ls * SL, Sz);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) pw[v] = fma(wl[ls], Sx[v] + (Sy[v] + Sz[v]), pw[v]);
+                    }
+                    if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q);
+                }
+            });
+        }
         // ---- time averages (A.3): qbar | Fbar_x | Fbar_y | Fbar_z (| time-averaged source), node-major images of stride FS
         bar();                                               // every fold has read its sums: the closing image reuses the LDS
         if (owner) {
@@ -613,13 +801,19 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[l][v];
                 static_for<0, DIM>([&](auto dc) {
                     constexpr int D = decltype(dc)::value;
-                    PDE::template flux<D>(q[l], a, F);
+                    if constexpr (XT) {
+                        double xo[3];
+                        owner_x(xo);
+                        dg_flux_xt<PDE>(q[l], xo, level_t(l), D, F);
+                    } else {
+                        PDE::template flux<D>(q[l], a, F);
+                    }
 #pragma unroll
                     for (int v = 0; v < NV; v++) Fb[D][v] += wm[l] * F[v];
                 });
                 if constexpr (pde_has_source<PDE>::value) {
                     double Sq[NV];
-                    PDE::source(q[l], Sq);
+                    source_at(q[l], l, Sq);
 #pragma unroll
                     for (int v = 0; v < NV; v++) Sbar[v] += wm[l] * Sq[v];
                 }
@@ -692,6 +886,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
 #pragma unroll
             for (int v2 = 0; v2 < NV; v2++) {
                 us[v2] = ukeep[v2];
+                if constexpr (NCP) us[v2] -= dt * pw[v2];
                 if constexpr (pde_has_source<PDE>::value) us[v2] += dt * EXA_LD((4 * NV + v2) * FS + o_n);
 #pragma unroll
                 for (int d = 0; d < DIM; d++) us[v2] += EXA_LD(((1 + d) * NV + v2) * FS + o_n);

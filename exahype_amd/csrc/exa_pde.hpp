@@ -66,6 +66,28 @@ template <class PDE> __device__ inline void fv_ncp(const double* q, const double
     else PDE::ncp(q, dq, d, out);
 }
 
+// The same terms for the ADER-DG kernels (tolerance 1e-10): generated term sets carry `_fast` twins whose reciprocals / square roots use the
+// fast sequences below (pde_codegen.py); a term set without them is evaluated as it is.
+template <class P, class = void> struct pde_has_fast_xt : std::false_type {};
+template <class P> struct pde_has_fast_xt<P, std::void_t<decltype(&P::flux_xt_fast)>> : std::true_type {};
+template <class P, class = void> struct pde_has_fast_ncp : std::false_type {};
+template <class P> struct pde_has_fast_ncp<P, std::void_t<decltype(&P::ncp_fast)>> : std::true_type {};
+template <class P, class = void> struct pde_has_fast_ncp_xt : std::false_type {};
+template <class P> struct pde_has_fast_ncp_xt<P, std::void_t<decltype(&P::ncp_xt_fast)>> : std::true_type {};
+template <class PDE> __device__ inline void dg_flux_xt(const double* q, const double* x, double t, int d, double* F) {
+    if constexpr (pde_has_fast_xt<PDE>::value) PDE::flux_xt_fast(q, x, t, d, F);
+    else PDE::flux_xt(q, x, t, d, F);
+}
+template <class PDE> __device__ inline void dg_ncp(const double* q, const double* dq, const double* x, double t, int d, double* out) {
+    if constexpr (pde_has_xt<PDE>::value) {
+        if constexpr (pde_has_fast_ncp_xt<PDE>::value) PDE::ncp_xt_fast(q, dq, x, t, d, out);
+        else PDE::ncp_xt(q, dq, x, t, d, out);
+    } else {
+        if constexpr (pde_has_fast_ncp<PDE>::value) PDE::ncp_fast(q, dq, d, out);
+        else PDE::ncp(q, dq, d, out);
+    }
+}
+
 // 1/x from v_rcp_f64 + EXA_RCP_NR Newton steps.  Measured on MI355X against the IEEE quotient
 // (scripts/rcp_accuracy.hip, 4M values): bare v_rcp_f64 2.6e8 ulp, one step <= 11 ulp (2.5e-15 relative), two
 // steps exact.  One step is the default: used by the ADER-DG kernels only (tolerance 1e-10; 2 % of stage A);

@@ -1274,7 +1274,7 @@ static int fv_mode(int mode, int P, int H, int m, int V, long n_patches, double*
         }
     }
     if constexpr (pde_has_xt<PDE>::value) {
-        if (slot) { set_error("FV Rusanov: the masked patch update carries no patch centres / time; term sets whose terms depend on position / time are not served"); return -1; }
+        if (slot && !cd.centre) { set_error("FV Rusanov: the masked patch update of a term set whose terms depend on position / time needs the patch centres (exa_fv_time_step_device_masked_at)"); return -1; }
     }
     if (cd.grid_on) return fv_dispatch<DIM, PDE, 1, true>(P, H, m, V, n_patches, Q, dt, h, slot, s, cd);
     return fv_dispatch<DIM, PDE, 1, false>(P, H, m, V, n_patches, Q, dt, h, slot, s, cd);

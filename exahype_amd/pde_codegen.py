@@ -337,13 +337,21 @@ class SympyPDE:
                 src_member += ("    __device__ static inline void source(const double* q, double* S) { const double x0[3] = {0.0, 0.0, 0.0}; "
                                "source_xt(q, x0, 0.0, S); }\n")
         if self.ncp_exprs is not None:
-            cases = ["        case %d: {\n%s\n        } break;" % (d, self._block(self.ncp_exprs[d], ["out[%d]" % v for v in range(n)], "            "))
-                     for d in range(self.max_dim)]
-            sig = "ncp_xt(const double* q, const double* dq, const double* x, double t, int d, double* out)" if self.uses_xt \
-                else "ncp(const double* q, const double* dq, int d, double* out)"
-            src_member += ("    static constexpr bool HAS_NCP = true;\n    __device__ static inline void %s {\n        switch (d) {\n%s\n"
-                           "        default:\n            for (int v = 0; v < NV; v++) out[v] = 0.0;\n        }\n    }\n" % (sig, "\n".join(cases)))
+            for fast in (False, True):
+                cases = ["        case %d: {\n%s\n        } break;" % (d, self._block(self.ncp_exprs[d], ["out[%d]" % v for v in range(n)], "            ", fast=fast))
+                         for d in range(self.max_dim)]
+                nm = "ncp_xt" if self.uses_xt else "ncp"
+                sig = ("%s%s(const double* q, const double* dq, const double* x, double t, int d, double* out)" if self.uses_xt
+                       else "%s%s(const double* q, const double* dq, int d, double* out)") % (nm, "_fast" if fast else "")
+                src_member += ("%s    __device__ static inline void %s {\n        switch (d) {\n%s\n"
+                               "        default:\n            for (int v = 0; v < NV; v++) out[v] = 0.0;\n        }\n    }\n"
+                               % ("" if fast else "    static constexpr bool HAS_NCP = true;\n", sig, "\n".join(cases)))
         if self.uses_xt:
+            fast_cases = ["        case %d: {\n%s\n        } break;" % (d, self._block(self.flux_exprs[d], ["F[%d]" % v for v in range(n)], "            ", fast=True))
+                          for d in range(self.max_dim)]
+            src_member += ("    // (the ADER-DG kernels' twin of flux_xt: reciprocals / square roots by the fast sequences, tolerance 1e-10)\n"
+                           "    __device__ static inline void flux_xt_fast(const double* q, const double* x, double t, int d, double* F) {\n        switch (d) {\n%s\n"
+                           "        default:\n            for (int v = 0; v < NV; v++) F[v] = 0.0;\n        }\n    }\n" % "\n".join(fast_cases))
             return self._source_xt(flux_cases, eig_cases, src_member)
         return self._source_tuned(flux_cases, eig_cases, src_member)
 
@@ -451,11 +459,11 @@ namespace exa {
 struct UserPDE {
     static constexpr int NV = %d;
     static constexpr int NFLUX = %d;
-    static constexpr int NAUX = 1;
+    static constexpr int NAUX = 0;             // (nothing cached: the terms are evaluated where the node's position and the level's time are known)
     static constexpr int MAXDIM = %d;
     static constexpr bool HAS_XT = true;
-    __device__ static inline void aux(const double*, double* a) { a[0] = 0.0; }
-    __device__ static inline void aux_fast(const double*, double* a) { a[0] = 0.0; }
+    __device__ static inline void aux(const double*, double*) {}
+    __device__ static inline void aux_fast(const double*, double*) {}
     __device__ static inline void flux_xt(const double* q, const double* x, double t, int d, double* F) {
         switch (d) {
 %s

@@ -68,7 +68,13 @@ class FVRusanovKernel:
             if not (slot.is_cuda and slot.dtype == torch.int64 and slot.is_contiguous() and slot.numel() >= self.shape[0]):
                 raise ValueError("slot must be a contiguous int64 CUDA tensor with one entry per patch")
             if centres is not None or t != 0.0:
-                raise ValueError("the masked patch update (slot=) carries no patch centres / time")
+                dim = len(self.shape) - 2
+                if centres is None or not (isinstance(centres, torch.Tensor) and centres.is_cuda and centres.dtype == torch.float64 and centres.is_contiguous()
+                                           and centres.numel() == self.shape[0] * dim):
+                    raise ValueError("the masked patch update with coordinates needs centres: a contiguous float64 CUDA tensor [n_patches][dim]")
+                check(self.lib.exa_fv_time_step_device_masked_at(self._plan, C.c_void_p(Q.data_ptr()), C.c_void_p(slot.data_ptr()),
+                                                                 C.c_void_p(centres.data_ptr()), t, dt, h, _stream_ptr()))
+                return Q
             check(self.lib.exa_fv_time_step_device_masked(self._plan, C.c_void_p(Q.data_ptr()), C.c_void_p(slot.data_ptr()),
                                                           dt, h, _stream_ptr()))
             return Q
@@ -833,9 +839,8 @@ class SubcellLimiter:
         would be 51 GB).  A step with more troubled cells than that is reported by check(): construct the limiter again with a
         larger capacity (capacity=n_cells serves every mask).  Raises if the patch array does not fit the free device memory."""
         torch = _torch()
-        if solver.lib.exa_pde_flags(int(solver.pde)) & 1:
-            raise NotImplementedError("SubcellLimiter: the patch update of the troubled cells carries no coordinates; term sets whose terms depend on "
-                                      "position / time are not served")
+        # term sets whose terms depend on position / time: the patch update of a troubled cell gets the cell's centre and the step's start time
+        self._xt = bool(solver.lib.exa_pde_flags(int(solver.pde)) & 1)
         self.s = solver
         self.Ns = 2 * solver.N - 1
         self.patch_doubles = solver.lib.exa_lim_patch_count(solver._plan)
@@ -969,8 +974,18 @@ class SubcellLimiter:
         patches = self._patches
         check(s.lib.exa_dg_project_patches_ghost(s._plan, C.c_void_p(s.u.data_ptr()), C.c_void_p(cells.data_ptr()), cap,
                                                  C.c_void_p(patches.data_ptr()), ghosts, _stream_ptr()))
+        t0 = s.time
         s.step(dt)                                             # candidate DG solution everywhere
-        self._fv.time_step(patches.reshape(-1), dt, s.dx[0] / self.Ns, slot=cells)
+        if self._xt:
+            # centre of the patch in slot k = centre of its DG cell (device ops on the compacted list; unused slots: any value)
+            c = cells[:cap].clamp(min=0)
+            cen = torch.empty((cap, s.dim), dtype=torch.float64, device=s.dev)
+            for a in range(s.dim - 1, -1, -1):
+                cen[:, a] = s.origin[a] + ((c % s.nc[a]).to(torch.float64) + 0.5) * s.dx[a]
+                c = c // s.nc[a]
+            self._fv.time_step(patches.reshape(-1), dt, s.dx[0] / self.Ns, slot=cells, t=t0, centres=cen)
+        else:
+            self._fv.time_step(patches.reshape(-1), dt, s.dx[0] / self.Ns, slot=cells)
         check(s.lib.exa_dg_reconstruct_patches(s._plan, C.c_void_p(patches.data_ptr()), C.c_void_p(cells.data_ptr()), cap,
                                                C.c_void_p(s.u.data_ptr()), _stream_ptr()))
         return count

@@ -104,6 +104,10 @@ int exa_fv_time_step_device(exa_fv_plan* plan, double* Q_dev, double dt, double 
  * patch p with slot_dev[p] < 0.  slot_dev == NULL: all patches (== exa_fv_time_step_device). */
 int exa_fv_time_step_device_masked(exa_fv_plan* plan, double* Q_dev, const long* slot_dev, double dt, double h,
                                    void* stream);
+/* ... with the patch centres ([n_patches][dim], entries of unused patches ignored) and the time, for term sets whose terms depend on position /
+ * time (the limiter's troubled cells of such a system: the centre of a patch is the centre of its DG cell) */
+int exa_fv_time_step_device_masked_at(exa_fv_plan* plan, double* Q_dev, const long* slot_dev, const double* centre_dev, double t, double dt,
+                                      double h, void* stream);
 
 /* The `exahype2::CellData` flavour of the kernel (`examples/kernel-generator.py:6-45`; `exahype/KernelBuilder.py:217-218`: the output item is
  * indexed without the halo; `Unit test/correctness_test.cpp:142`: CellData(QIn, cellCentre, cellSize, t, dt, QOut)): QIn_dev
