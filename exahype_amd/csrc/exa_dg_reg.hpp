@@ -58,6 +58,10 @@ template <class PDE> struct DirFlux<PDE, false> {
 #ifndef EXA_REG_PRIO
 #define EXA_REG_PRIO 1
 #endif
+#ifndef EXA_REG_CPW
+#define EXA_REG_CPW 2                          // cells in flight per workgroup: 2 = one 512-thread workgroup per CU, halves one barrier apart (128^3 cells:
+#endif                                         // 154.5 ms; 1 = two 256-thread workgroups: 158.9 ms)
+#define EXA_REG_CPW_DEFAULT EXA_REG_CPW
 
 template <int N> struct RegGeo {
     static constexpr int NN = N * N * N, NF = N * N;
@@ -124,8 +128,13 @@ __device__ inline void lds_barrier() {
 // face node (216 face nodes = 216 lanes) are requested during the previous cell's closing phases and stay in flight across its barriers
 // (which wait for LDS operations only in this variant).  Sequence of a run: A, [B o A] x (n - 1), B.
 
+// Term sets with a non-conservative product run ONE cell per workgroup at one wave per SIMD (REG_CPW_OF = 1, second launch bound 1): the ncp part
+// of the derive phase needs the six states of a pencil at once on top of the owner state, ~290 VGPRs -- at two waves per SIMD (256) that was 288
+// spilled registers and 30.5 ms per 32^3 launch of Euler-with-pressure-as-ncp, slower than the plain kernel (26.3); a lone wave has the SIMD's 512
+// registers (the allocator parks the excess in accumulation registers instead of scratch).
+template <class PDE> constexpr int REG_CPW_OF = pde_has_ncp<PDE>::value ? 1 : EXA_REG_CPW_DEFAULT;
 template <int N, class PDE, int CPW, bool FUSE = false>
-__global__ void __launch_bounds__(256 * CPW, 2)
+__global__ void __launch_bounds__(256 * CPW, (pde_has_ncp<PDE>::value ? 1 : 2))
 dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ trace,
                       long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
                       const void* __restrict__ ops_raw, const int* __restrict__ tab, const void* __restrict__ step_raw, RegFuse fz, PlainGeo geo) {
