@@ -373,7 +373,7 @@ def run_cfg2(a, torch, exa, world, rank, local, pde=None):
         out["devices"] = names
         out["exchange_ms"] = max(float(v[0]) for v in allv)              # RCCL span only; the pack copies are `pack_ms`
         out["pack_ms"] = max(float(v[4]) for v in allv)
-        out["high_priority_comm"] = {"comm_stream": True, "nccl_process_group_stream": bool(a.backend == "nccl")}
+        out["high_priority_comm"] = {"comm_stream": True, "nccl_process_group_stream": bool(a.backend == "nccl" and os.environ.get("EXA_NCCL_STREAM_PRIORITY", "normal") == "high")}
         if reserve_trial is not None:
             out["reserve_cus_chosen"] = s.reserve_cus
             out["reserve_cus_trial"] = {str(k): v for k, v in reserve_trial.items()}
@@ -598,8 +598,12 @@ def run_fv_grid(a, torch, exa, local):
 
 
 def nccl_options():
+    """RCCL's transport kernels run on the process group's own stream.  The round-3 review asked for a high-priority one; measured on the
+    RCCL-to-self rehearsal (profiles/r04_bench_cfg2_self_exchange*.json) it is WORSE: the send / recv group then completes only when the
+    persistent interior launch retires (span 146.9 ms, 0.17 ms exposed) where the normal-priority stream behind the solver's high-priority comm
+    stream is done after 0.31 ms (0.0 exposed).  Default: normal; EXA_NCCL_STREAM_PRIORITY=high for a node where it measures otherwise."""
     import torch.distributed as dist
-    return dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    return dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("EXA_NCCL_STREAM_PRIORITY", "normal") == "high")
 
 
 def main():
@@ -650,8 +654,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
-            # RCCL's transport kernels run on the process group's OWN stream (not on the solver's comm stream, which only orders them): ask
-            # for a high-priority one, so that they are dispatched ahead of the interior launch's remaining workgroups
+            # RCCL's transport kernels run on the process group's OWN stream (not on the solver's comm stream, which only orders them): its
+            # priority is a measured choice, see nccl_options()
             dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=nccl_options())
         else:
             dist.init_process_group(a.backend)

@@ -34,12 +34,12 @@ PY
 echo "== bench lines"; 
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; tail -c 600 $OUT/bench_cfg2.json; echo
 python3 bench.py --gpus 1 --self-exchange --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg2_self_exchange.json 2> $OUT/bench_cfg2_self_exchange.err; tail -c 400 $OUT/bench_cfg2_self_exchange.json; echo
-for cfg in cfg1 cfg4 fv-ref; do python3 bench.py --config $cfg --steps 10 --warmup 3 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; tail -c 300 $OUT/bench_$cfg.json; echo; done
+for cfg in cfg1 cfg4 fv-ref fv-grid cfg2_sympy cfg4_sympy; do python3 bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; tail -c 300 $OUT/bench_$cfg.json; echo; done
 echo "== kernel trace of the headline command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/trace_cfg2.log 2>&1
 find $OUT/trace_cfg2 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_cfg2.csv \;
 head -8 $OUT/kernel_stats_cfg2.csv
-for cfg in cfg1 cfg4 fv-ref; do
+for cfg in cfg1 cfg4 fv-ref fv-grid cfg2_sympy; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$cfg -- python3 bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace_$cfg.log 2>&1
   find $OUT/trace_$cfg -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$cfg.csv \;
   head -5 $OUT/kernel_stats_$cfg.csv
@@ -49,6 +49,9 @@ traffic cfg2 dg_stage_a_reg_kernel '{"kernel": "dg_stage_a_reg_kernel<6, exa::Eu
 traffic cfg1 dg_fused_single_kernel '{"algorithmic_bytes_per_launch": 1006632960.0}' -- --config cfg1 --steps 5 --warmup 2
 traffic cfg4 dg_stage_a_m8_kernel '{"kernel": "dg_stage_a_m8_kernel<exa::Euler>", "cells": 64}' -- --config cfg4 --steps 2 --warmup 1
 traffic fv_ref fv_rusanov_kernel '{"algorithmic_bytes_per_launch": 3690987520.0}' -- --config fv-ref --steps 5 --warmup 2
+# the grid step on halo-less arrays (r4): every state read once, written once = 16 V B per volume
+traffic fv_grid_4x4 'exa::FvShape<4, 1, 5, 10>, true, true>' '{"algorithmic_bytes_per_launch": 2684354560.0, "note": "2^20 patches 4x4, 10 variables: 16 x 10 B x 16 volumes"}' -- --config fv-grid --steps 10 --warmup 3
+traffic fv_grid_15 'fv_rusanov_slab_kernel<exa::Euler, 1, true, false, true>' '{"algorithmic_bytes_per_launch": 2211840000.0, "note": "8192 patches 15^3, 5 variables"}' -- --config fv-grid --steps 10 --warmup 3
 # the limiter's FV patch kernel (15^3 patches) inside cfg4
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys
