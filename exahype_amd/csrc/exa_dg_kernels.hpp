@@ -160,6 +160,13 @@ __device__ unsigned long long g_exa_wg_span[2 * 1024];     // per workgroup: sta
 #else
 #define EXA_ABL_COND_SKIP_D
 #endif
+// Stage B: the eigenvalues of the trace states by the IEEE sequences (default) or by the fast reciprocal / square root.  Measured r4 (same box, two
+// rounds, scripts/quick_bench_stage_b.py): 128^3 p = 5 15.70 / 15.85 ms IEEE against 16.52 / 16.50 fast (the dense variant LOSES 4 %: the kernel is
+// bound by its memory latency chain, and the shorter arithmetic changes nothing but the schedule), 64^3 p = 7 4.07 / 4.10 against 3.98 / 4.05, 128^3 p = 3
+// 5.96 / 6.09 against 6.05 / 6.04 -- not adopted.
+#ifndef EXA_STAGE_B_FAST_EIG
+#define EXA_STAGE_B_FAST_EIG 0
+#endif
 #ifdef EXA_ABL_NOFMA
 #define EXA_FMA(acc, a, b) asm volatile("" : "+v"(acc) : "v"(a), "v"(b))
 #else
@@ -1217,7 +1224,11 @@ dg_stage_b_kernel(double* __restrict__ u, const double* __restrict__ trace, Stag
                 Fm[v] = pm[(NV + v) * NF + y];
                 Fp[v] = pp[(NV + v) * NF + y];
             }
+#if EXA_STAGE_B_FAST_EIG
+            lam = fmax(PDE::maxeig_fast(qm, d), PDE::maxeig_fast(qp, d));
+#else
             lam = fmax(PDE::maxeig(qm, d), PDE::maxeig(qp, d));
+#endif
         }
         // face-wide maximum: segmented butterfly over the GS lanes of the face (inactive lanes carry 0)
 #pragma unroll
@@ -1349,7 +1360,11 @@ dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace
                 face_node_coords<DIM, N>(geo, cc, d, face, y, xf);
                 lam[task] = fmax(PDE::maxeig_xt(qm[k], xf, geo.t + 0.5 * dt, d), PDE::maxeig_xt(qp[k], xf, geo.t + 0.5 * dt, d));
             } else {
+#if EXA_STAGE_B_FAST_EIG
+                lam[task] = fmax(PDE::maxeig_fast(qm[k], d), PDE::maxeig_fast(qp[k], d));
+#else
                 lam[task] = fmax(PDE::maxeig(qm[k], d), PDE::maxeig(qp[k], d));
+#endif
             }
         }
     }
