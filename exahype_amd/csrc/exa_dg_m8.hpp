@@ -71,6 +71,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
     // two nodes get B_D(q) (D q) / h_D from two more matrix instructions per variable on q itself, the time-averaged ncp term is one more pass of
     // the derive rounds over the final iterate.  Under `if constexpr`: the built-in term sets compile to the same code as before.
     constexpr bool XT = pde_has_xt<PDE>::value, NCP = pde_has_ncp<PDE>::value;
+    constexpr bool FXT = pde_flux_xt<PDE>::value;                     // the flux itself sees x, t (otherwise only the source / ncp do)
     using G = M8Geo;
     using SA = StageAM8<PDE>;
     constexpr int NV = SA::NV, NA = SA::NA, NN = G::NN, NF = G::NF, SL = G::SL, VS = SA::VS, QSZ = SA::QSZ, AXO = SA::AXO, NT = SA::NT, LS = SA::LS;
@@ -173,7 +174,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 tl = ls ? tB : tA;
             }
             if constexpr (MODE == 0) {
-                if constexpr (XT) {
+                if constexpr (FXT) {
                     dg_flux_xt<PDE>(qa, xa, tl, D, Fa);
                     dg_flux_xt<PDE>(qb, xb, tl, D, Fb);
 #pragma unroll
@@ -502,7 +503,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[l][v];
                 static_for<0, DIM>([&](auto dc) {
                     constexpr int D = decltype(dc)::value;
-                    if constexpr (XT) {
+                    if constexpr (FXT) {
                         double xo[3];
                         owner_x(xo);
                         dg_flux_xt<PDE>(q[l], xo, level_t(l), D, F);

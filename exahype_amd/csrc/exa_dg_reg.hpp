@@ -143,6 +143,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     // the source, B_d(q) (D q)_i / h_d joins the derivative sums of the pencil's nodes, the time-averaged ncp term is one more pass of the
     // derive phase over the final iterate.  Everything under `if constexpr`: the built-in term sets compile to the same code as before.
     constexpr bool XT = pde_has_xt<PDE>::value, NCP = pde_has_ncp<PDE>::value;
+    constexpr bool FXT = pde_flux_xt<PDE>::value;                     // the flux itself sees x, t (otherwise only the source / ncp do)
     static_assert(!(FUSE && (XT || NCP)), "the one-kernel step is built for term sets without coordinates / ncp");
     using G = RegGeo<N>;
     using SA = StageAReg<N, PDE, CPW>;
@@ -287,7 +288,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
 #pragma unroll
             for (int j = 0; j < H; j++) {
                 double Fa[NV], Fb[NV];
-                if constexpr (XT) {
+                if constexpr (FXT) {
                     double xj[3];
                     pencil_x(tk, dd, j, xj);
                     dg_flux_xt<PDE>(qa[j], xj, tl, dd, Fa);
@@ -408,7 +409,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     using M1 = std::integral_constant<int, 1>;                       // ... only their non-conservative part
     // (ncp term sets keep the run-time direction: at their register pressure the three copies of the flux part measured slower, 34.6 against 26.1 ms
     //  per 32^3 launch of Euler with its pressure gradient as an ncp)
-    constexpr bool SPLIT_DIR = !NCP && (XT || !pde_has_dir<PDE>::value);
+    constexpr bool SPLIT_DIR = !NCP && (FXT || !pde_has_dir<PDE>::value);
     auto derive = [&](const Task& tk, const DirFlux<PDE>& fx, const double (&Em)[NE], double tA, double tB, auto mode) {
         // the derive stream is the long one of a step: it gets the SIMD's issue slots ahead of the co-resident wave of the other cell in
         // flight (in its fold / load / closing segment) -- 8 % of the launch (profiles/r03_reg_kernel.txt)
@@ -810,7 +811,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 for (int v = 0; v < NV; v++) qb[v] += wm[l] * q[l][v];
                 static_for<0, DIM>([&](auto dc) {
                     constexpr int D = decltype(dc)::value;
-                    if constexpr (XT) {
+                    if constexpr (FXT) {
                         double xo[3];
                         owner_x(xo);
                         dg_flux_xt<PDE>(q[l], xo, level_t(l), D, F);

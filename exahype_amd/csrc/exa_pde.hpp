@@ -43,6 +43,10 @@ template <class P> struct pde_has_source<P, std::void_t<decltype(P::HAS_SOURCE)>
 // term sets have none, and for them the coordinates below are dead code: their kernels are unchanged.
 template <class P, class = void> struct pde_has_xt : std::false_type {};
 template <class P> struct pde_has_xt<P, std::void_t<decltype(P::HAS_XT)>> : std::bool_constant<P::HAS_XT> {};
+// ... and whether the FLUX is among them (a generated term set says FLUX_XT = false when only its source / eigenvalue see x, t: the ADER-DG kernels then
+// use its tuned flux members and hand the coordinates to the source alone)
+template <class P, class = void> struct pde_flux_xt : pde_has_xt<P> {};
+template <class P> struct pde_flux_xt<P, std::void_t<decltype(P::FLUX_XT)>> : std::bool_constant<pde_has_xt<P>::value && P::FLUX_XT> {};
 template <class PDE> __device__ inline void fv_flux(const double* q, const double* x, double t, int d, double* F) {
     if constexpr (pde_has_xt<PDE>::value) PDE::flux_xt(q, x, t, d, F);
     else PDE::flux_rt(q, d, F);

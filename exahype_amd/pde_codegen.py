@@ -138,6 +138,7 @@ class SympyPDE:
             raise ValueError("n_vars must be 1..8")
         self.n_vars, self.max_dim, self.name = n_vars, max_dim, name
         self.max_aux = max_aux                      # cached flux scalars per node: None = as many as pay and fit (see _analyse)
+        self.dg_flags = None                        # development aid: compiler flags of the stage-A units instead of build.DG_SCHED
         self._aux = None
         self.q = self.state(n_vars)
         self.x = list(sympy.symbols("x0:3", real=True))
@@ -355,12 +356,8 @@ class SympyPDE:
             return self._source_xt(flux_cases, eig_cases, src_member)
         return self._source_tuned(flux_cases, eig_cases, src_member)
 
-    def _source_tuned(self, flux_cases, eig_cases, src_member):
-        """Term set of the state alone (no position / time, no ncp): the interface the tuned ADER-DG kernels are written against, with what
-        the hand-written exa::Euler has -- per-node cached scalars shared by the directions (aux / aux_fast), reciprocals and square roots by
-        the fast sequences in the members only the ADER-DG kernels call, the scale folded into the flux (flux_scaled), and the flux for a
-        per-LANE normal as straight-line code over per-lane masks (Dir / dir_init / flux_scaled_dir; exa_dg_reg.hpp) where that form costs
-        less than the divergent switch it replaces."""
+    def _tuned_flux_members(self):
+        """aux / aux_fast bodies, flux<D> / flux_scaled<D> branches and the Dir member for a flux that depends on the state alone"""
         self._analyse()
         n, na, md = self.n_vars, len(self._aux), self.max_dim
         sc = sympy.Symbol("sc")
@@ -393,6 +390,18 @@ class SympyPDE:
                               "        c.n[0] = d == 0 ? sc : 0.0;\n        c.n[1] = d == 1 ? sc : 0.0;\n        c.n[2] = d == 2 ? sc : 0.0;\n    }\n"
                               "    __device__ static inline void flux_scaled_dir(const double* q, const double* a, const Dir& c, double* F) {\n%s\n    }\n"
                               % (ops_m, ops_d, body))
+        return {"na": na, "aux_ieee": aux_ieee, "aux_fast": aux_fast, "flux_d": flux_d, "flux_sc": flux_sc, "dir_member": dir_member}
+
+    def _source_tuned(self, flux_cases, eig_cases, src_member):
+        """Term set of the state alone (no position / time, no ncp): the interface the tuned ADER-DG kernels are written against, with what
+        the hand-written exa::Euler has -- per-node cached scalars shared by the directions (aux / aux_fast), reciprocals and square roots by
+        the fast sequences in the members only the ADER-DG kernels call, the scale folded into the flux (flux_scaled), and the flux for a
+        per-LANE normal as straight-line code over per-lane masks (Dir / dir_init / flux_scaled_dir; exa_dg_reg.hpp) where that form costs
+        less than the divergent switch it replaces."""
+        m = self._tuned_flux_members()
+        n, na, md = self.n_vars, m["na"], self.max_dim
+        ind = "            "
+        aux_ieee, aux_fast, flux_d, flux_sc, dir_member = m["aux_ieee"], m["aux_fast"], m["flux_d"], m["flux_sc"], m["dir_member"]
         eig_fast = []
         for d in range(md):
             eig_fast.append("        case %d: {\n%s\n            return lam;\n        }" % (d, self._block([self.eig_exprs[d]], ["const double lam"], ind, fast=True)))
@@ -450,20 +459,58 @@ struct UserPDE {
 
     def _source_xt(self, flux_cases, eig_cases, src_member):
         """Term set whose expressions contain the volume centre x or the time t: the *_xt members carry them (fv_rusanov.hip uses them
-        where HAS_XT is set); the plain members evaluate at x = 0, t = 0 and exist only so that the common interface is complete."""
+        where HAS_XT is set).  Where the FLUX itself does not depend on x, t (a position- / time-dependent source or eigenvalue beside an ordinary
+        flux -- gravity, forcing) the ADER-DG kernels get the tuned flux interface of _source_tuned (cached scalars, scaled and per-lane-normal
+        forms; FLUX_XT = false) and hand the coordinates to the source only; otherwise the plain members evaluate flux_xt at x = 0, t = 0 and
+        exist only so that the common interface is complete."""
         n = self.n_vars
+        xt = set(self.x) | {self.t}
+        flux_xt_dep = any(e.free_symbols & xt for f in self.flux_exprs for e in f)
+        if flux_xt_dep:
+            naux, members = 0, """    static constexpr bool FLUX_XT = true;
+    __device__ static inline void aux(const double*, double*) {}
+    __device__ static inline void aux_fast(const double*, double*) {}
+    template <int D> __device__ static inline void flux(const double* q, const double*, double* F) { flux_rt(q, D, F); }
+    template <int D> __device__ static inline void flux_scaled(const double* q, const double*, double sc, double* F) {
+        flux_rt(q, D, F);
+#pragma unroll
+        for (int v = 0; v < NV; v++) F[v] *= sc;
+    }
+"""
+        else:
+            m = self._tuned_flux_members()
+            naux = m["na"]
+            members = """    static constexpr bool FLUX_XT = false;        // the flux sees the state alone: tuned forms below, coordinates reach the source / eigenvalue only
+    __device__ static inline void aux(const double* q, double* a) {
+%s
+    }
+    __device__ static inline void aux_fast(const double* q, double* a) {
+%s
+    }
+    template <int D> __device__ static inline void flux(const double* q, const double* a, double* F) {
+%s
+        if constexpr (D >= MAXDIM) {
+            for (int v = 0; v < NV; v++) F[v] = 0.0;
+        }
+    }
+    template <int D> __device__ static inline void flux_scaled(const double* q, const double* a, double sc, double* F) {
+%s
+        if constexpr (D >= MAXDIM) {
+            for (int v = 0; v < NV; v++) F[v] = 0.0;
+        }
+    }
+%s""" % (m["aux_ieee"], m["aux_fast"], "\n".join(m["flux_d"]), "\n".join(m["flux_sc"]), m["dir_member"])
         return """// generated by exahype_amd/pde_codegen.py from SymPy expressions -- user PDE term set "%s" (terms depend on position / time)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "exa_pde.hpp"
 namespace exa {
 struct UserPDE {
     static constexpr int NV = %d;
     static constexpr int NFLUX = %d;
-    static constexpr int NAUX = 0;             // (nothing cached: the terms are evaluated where the node's position and the level's time are known)
+    static constexpr int NAUX = %d;
     static constexpr int MAXDIM = %d;
     static constexpr bool HAS_XT = true;
-    __device__ static inline void aux(const double*, double*) {}
-    __device__ static inline void aux_fast(const double*, double*) {}
     __device__ static inline void flux_xt(const double* q, const double* x, double t, int d, double* F) {
         switch (d) {
 %s
@@ -478,17 +525,11 @@ struct UserPDE {
         return 0.0;
     }
     __device__ static inline void flux_rt(const double* q, int d, double* F) { const double x0[3] = {0.0, 0.0, 0.0}; flux_xt(q, x0, 0.0, d, F); }
-    template <int D> __device__ static inline void flux(const double* q, const double*, double* F) { flux_rt(q, D, F); }
-    template <int D> __device__ static inline void flux_scaled(const double* q, const double*, double sc, double* F) {
-        flux_rt(q, D, F);
-#pragma unroll
-        for (int v = 0; v < NV; v++) F[v] *= sc;
-    }
-    __device__ static inline double maxeig(const double* q, int d) { const double x0[3] = {0.0, 0.0, 0.0}; return maxeig_xt(q, x0, 0.0, d); }
+%s    __device__ static inline double maxeig(const double* q, int d) { const double x0[3] = {0.0, 0.0, 0.0}; return maxeig_xt(q, x0, 0.0, d); }
     __device__ static inline double maxeig_fast(const double* q, int d) { return maxeig(q, d); }
 %s};
 }  // namespace exa
-""" % (self.name, n, n, self.max_dim, "\n".join(flux_cases), "\n".join(eig_cases), src_member)
+""" % (self.name, n, n, naux, self.max_dim, "\n".join(flux_cases), "\n".join(eig_cases), members, src_member)
 
     def key(self):
         h = hashlib.sha256(self.source().encode())
@@ -496,6 +537,7 @@ struct UserPDE {
                   "exa_dg_common.hpp", "exa_launch.hpp", "exa_pde.hpp", "exa_dg_plain.hpp", "exa_dg_m8.hpp"):
             h.update(open(os.path.join(CSRC, f), "rb").read())
         h.update(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "build.py"), "rb").read())      # (compiler flags)
+        h.update(repr(self.dg_flags).encode())
         return h.hexdigest()[:16]
 
     # -- build + registration ----------------------------------------------------------------------
@@ -519,10 +561,11 @@ struct UserPDE {
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         common = [hipcc, "-O3", "-fPIC", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-Wno-unused-function",
                   "-Wno-pass-failed", "-I", CSRC, "-DEXA_PDE_ID=100", '-DEXA_USER_PDE_HEADER="%s"' % hdr]
-        units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"]), ("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2", "-DEXA_UNIT_A"] + _build.DG_SCHED),
+        sched = self.dg_flags if self.dg_flags is not None else _build.DG_SCHED
+        units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"]), ("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2", "-DEXA_UNIT_A"] + sched),
                  ("dg_inst.hip", "dg2b.o", ["-DEXA_DIM=2", "-DEXA_UNIT_B"])]
         if self.max_dim >= 3:
-            units += [("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3", "-DEXA_UNIT_A"] + _build.DG_SCHED), ("dg_inst.hip", "dg3b.o", ["-DEXA_DIM=3", "-DEXA_UNIT_B"])]
+            units += [("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3", "-DEXA_UNIT_A"] + sched), ("dg_inst.hip", "dg3b.o", ["-DEXA_DIM=3", "-DEXA_UNIT_B"])]
         procs = [(o, subprocess.Popen(common + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(d, o)],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for src, o, extra in units]
         for o, p in procs:

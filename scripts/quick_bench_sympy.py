@@ -9,6 +9,8 @@ from bench import sympy_euler as euler_sympy
 N, nc = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 spde = euler_sympy()
+if os.environ.get("EXA_USER_DG_FLAGS") is not None:              # e.g. "" (default scheduling) or "-mllvm -amdgpu-sched-strategy=max-memory-clause"
+    spde.dg_flags = os.environ["EXA_USER_DG_FLAGS"].split()
 pid = spde.register()
 res = {}
 order = (("built-in", exa.PDE_EULER), ("sympy", pid))
