@@ -658,7 +658,7 @@ class FVPatchGrid:
     neighbour's interior layers (periodic wrap, or the prescribed state on a domain face with `boundary=`), and writes the new states to a
     second array; the two swap (`self.U` is rebound: fetch it again after a step).  No halo pass and no halo bytes in HBM.  run(t_end) takes dt
     from the CFL condition: the kernel that writes the new states reduces their eigenvalues on the way, so a step costs ONE host read of one
-    double and no scan pass.  `Q` (property) materialises the reference layout with halo -- interiors + filled halo layers -- for a caller who
+    double and no scan pass.  `with_halo()` materialises the reference layout with halo -- interiors + filled halo layers -- for a caller who
     wants it (output, the plain `time_step` entry points).  fused=False keeps the two-pass form on an array with halo (halo fill by torch ops,
     then the in-place update): the comparison the tests and the benchmark use."""
 
@@ -709,10 +709,19 @@ class FVPatchGrid:
 
     @property
     def Q(self):
-        """[g.., S.., V] with halo (S = P + 2 H).  fused: a COPY with the halo layers filled from the neighbours / the boundary states;
-        two-pass form: the array itself (halo layers as the last fill left them)."""
+        """two-pass form: the array with halo itself, [g.., S.., V] (halo layers as the last fill left them).  The fused form has no such array
+        (writing into a copy would be lost without a word): `with_halo()` builds one, `U` is where the states live."""
         if not self.fused:
             return self._Q
+        raise AttributeError("FVPatchGrid keeps its states halo-less in `.U` [g.., P.., V]; `.with_halo()` returns a copy in the layout with halo "
+                             "(`fused=False` keeps the array with halo as `.Q`)")
+
+    def with_halo(self):
+        """A NEW array [g.., S.., V] in the reference layout (S = P + 2 H): interiors + the halo layers filled from the neighbours' boundary layers /
+        the boundary states -- what `time_step` expects of its caller."""
+        if not self.fused:
+            self.fill_halos()
+            return self._Q.clone()
         torch = _torch()
         S = self.P + 2 * self.H
         Q = torch.zeros(self.grid + (S,) * self.dim + (self.n_real + self.n_aux,), dtype=torch.float64, device=self.dev)

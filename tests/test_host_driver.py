@@ -174,6 +174,11 @@ def _grid_state(grid, P, V, seed, dim):
     (3, (3, 2, 2), 15, 1, 0, "rusanov", False),     # cfg 4's limiter patch: plane-streaming kernel, cached scalars
     (3, (2, 2, 3), 15, 1, 0, "faithful", True),     # ... its faithful form, domain faces with prescribed states
     (3, (1, 2, 1), 12, 1, 2, "rusanov", False),     # a grid extent of 1: the patch is its own neighbour
+    (2, (1, 1), 4, 1, 5, "rusanov", False),         # ONE patch: every halo is its own far side
+    (2, (1, 7), 4, 1, 5, "rusanov", True),          # fewer patches than a block holds; extent 1 along the slow axis
+    (3, (2, 1, 3), 5, 2, 1, "rusanov", True),       # 3-D, two halo layers, 125 volumes per patch (two patches per block)
+    (2, (3, 2), 16, 1, 0, "rusanov", False),        # one patch per 256-thread workgroup, staged
+    (2, (2, 2), 24, 1, 3, "faithful", True),        # one patch per 1024-thread workgroup, staged
 ])
 def test_grid_step_equals_halo_fill_plus_patch_update(dim, grid, P, H, n_aux, mode, dirichlet):
     """exa_fv_grid_step_device (halo-less arrays; the states beyond a patch face taken from the neighbours inside the launch) is BIT-equal to
@@ -205,7 +210,9 @@ def test_grid_step_equals_halo_fill_plus_patch_update(dim, grid, P, H, n_aux, mo
     S = P + 2 * H
     co = np.indices((S,) * dim)
     read = sum(((co[x] < H) | (co[x] >= H + P)).astype(int) for x in range(dim)) <= 1        # (corners / edges: not part of the stencil)
-    assert np.array_equal(a.Q.cpu().numpy()[(slice(None),) * dim + (read,)], b.Q.cpu().numpy()[(slice(None),) * dim + (read,)])
+    assert np.array_equal(a.with_halo().cpu().numpy()[(slice(None),) * dim + (read,)], b.Q.cpu().numpy()[(slice(None),) * dim + (read,)])
+    with pytest.raises(AttributeError, match="halo-less"):
+        a.Q
     # the CFL scan: left behind by the kernel that wrote the states == a scan pass over the array == the host maximum
     lam_fused = a.max_eigenvalue()
     a.invalidate()
@@ -216,3 +223,43 @@ def test_grid_step_equals_halo_fill_plus_patch_update(dim, grid, P, H, n_aux, mo
         want = max(want, max(float(np.max(exa.pde_eval(pde, d, np.stack(list(bnd.values())))[1])) for d in range(dim)))
     assert lam_scan == want
     assert abs(lam_fused - want) <= 1e-12 * want          # (the plane-streaming kernel evaluates it with its fast reciprocal / square root)
+
+
+@pytest.mark.gpu
+def test_grid_step_arguments_are_checked():
+    import ctypes as C
+    import torch
+    from exahype_amd import solvers as exa
+    fv = exa.FVPatchGrid(2, (3, 2), 4, 1, 5, 0)
+    lib, plan = fv.lib, fv.kernel._plan
+    U = fv.U
+    other = torch.zeros_like(U)
+    grid = exa.larr([3, 2])
+    call = lambda q, qn, g: lib.exa_fv_grid_step_device(plan, C.c_void_p(q.data_ptr()), C.c_void_p(qn.data_ptr()), g, None, None, 0.0, 1e-3, fv.h, None, None)
+    assert call(U, U, grid) != 0 and b"array of their own" in lib.exa_last_error()
+    assert call(U, other, exa.larr([3, 3])) != 0 and b"patches" in lib.exa_last_error()
+    assert call(U, other, exa.larr([0, 6])) != 0
+    assert call(U, other, grid) == 0
+    # halo wider than the patch: the layers would reach past the face neighbour
+    wide = exa.FVRusanovKernel(2, 2, 3, 5, 0, 6, exa.PDE_EULER, exa.FV_RUSANOV)
+    assert lib.exa_fv_grid_step_device(wide._plan, C.c_void_p(U.data_ptr()), C.c_void_p(other.data_ptr()), grid, None, None, 0.0, 1e-3, 0.1, None, None) != 0
+    assert b"halo_size" in lib.exa_last_error()
+
+
+@pytest.mark.gpu
+def test_grid_step_with_a_generated_term_set_and_cfl_loop():
+    """The grid step through a user library (exa_user_fv_launch with the grid arguments) == the two-pass form; run() with the fused CFL scan takes
+    the same steps as run() with a scan pass per step."""
+    from exahype_amd import solvers as exa
+    from tests.test_user_pde import swe, swe_state
+    p = swe()
+    grid, P = (5, 4), 6
+    U0 = swe_state(grid + (P, P), 4)
+    a = exa.FVPatchGrid(2, grid, P, 1, 3, 0, p.register(), exa.FV_RUSANOV, fused=True)
+    b = exa.FVPatchGrid(2, grid, P, 1, 3, 0, p.register(), exa.FV_RUSANOV, fused=False)
+    a.set_interior(U0); b.set_interior(U0)
+    t_end = 0.02
+    na, nb_ = a.run(t_end, cfl=0.3), b.run(t_end, cfl=0.3)
+    assert na == nb_ and na >= 3 and abs(a.time - t_end) < 1e-15 and abs(b.time - t_end) < 1e-15
+    # the fused scan evaluates the eigenvalue with the same (IEEE) members on the same states: the same dt sequence, the same result
+    assert np.array_equal(a.interior(), b.interior())

@@ -576,21 +576,22 @@ def test_fv_host_driver_hands_patch_centres_and_time_to_the_terms():
     t = 0.3
     for dt in (1e-3, 2e-3):
         fv.fill_halos()
-        want = kern.time_step_oop(fv.Q.reshape((6,) + fv.Q.shape[2:]).clone(), dt, h, t=t, centres=torch.as_tensor(centres, device="cuda"))
+        want = kern.time_step_oop(fv.with_halo().reshape((6,) + fv.with_halo().shape[2:]), dt, h, t=t, centres=torch.as_tensor(centres, device="cuda"))
         fv.step(dt)
         t += dt
         assert np.max(np.abs(fv.interior().reshape(want.shape) - want.cpu().numpy())) < 1e-13
     assert abs(fv.time - t) < 1e-15
     # numpy in, with coordinates: staged through the device, the same update
     fv.fill_halos()
-    qn = np.ascontiguousarray(fv.Q.reshape((6,) + fv.Q.shape[2:]).cpu().numpy())
+    Qh0 = fv.with_halo()
+    qn = np.ascontiguousarray(Qh0.reshape((6,) + Qh0.shape[2:]).cpu().numpy())
     want = kern.time_step_oop(qn.copy(), 1e-3, h, t=t, centres=centres)
     kern.time_step(qn, 1e-3, h, t=t, centres=centres)
     assert np.max(np.abs(qn[:, H:H + P, H:H + P] - want)) < 1e-13
     # the CFL scan hands the volume centres and the time to the eigenvalue (exa_pde_eval_device_at)
     npde = NumpyXtPDE(p)
     xv = _volume_centres(centres, P, H, h, 2)
-    Qh = fv.Q
+    Qh = fv.with_halo()
     qa = Qh.reshape((6,) + Qh.shape[2:]).cpu().numpy()
     inner = (slice(None), slice(H, H + P), slice(H, H + P))              # (the scan looks at the grid's own volumes, not at halo copies at shifted positions)
     want_lam = max(np.max(np.abs(npde.maxeig(qa, xv, fv.time, d)[inner])) for d in range(2))
