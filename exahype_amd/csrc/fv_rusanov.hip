@@ -143,8 +143,11 @@ using FvRuntimeShape = FvShape<0, 0, 0, 0>;
 // condition) before it updates the current one from LDS -- the 46 KB read of a block overlaps the stencil and the
 // write-back of its predecessor instead of standing alone in front of a barrier.
 constexpr int FV_HR = 16;          // double2 per thread that hold a block in flight (<= 64 KiB per block at 256 threads)
+#ifndef EXA_FV_GRID_WAVES
+#define EXA_FV_GRID_WAVES 1          // persistent grid step: no register cap (199 VGPRs, two workgroups per CU: 0.855 ms per 2^20-patch step); capped at 168 for
+#endif                               // three workgroups per CU it spills 31 registers and takes 0.995 ms
 template <int DIM, class PDE, int MODE, int CPT, int NT, bool STAGE, class SHAPE = FvRuntimeShape, bool PERSIST = false, bool GRID = false>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, ((GRID && PERSIST && NT == 256) ? EXA_FV_GRID_WAVES : 1))
 fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt, double dt, double dt_over_h, long n_patches,
                   int ppb, const long* __restrict__ slot, FvCellData cd) {
     const int P = SHAPE::P ? SHAPE::P : P_rt, H = SHAPE::P ? SHAPE::H : H_rt;
@@ -203,7 +206,10 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
     };
     constexpr int PERC = SHAPE::P ? SHAPE::H * (DIM == 3 ? SHAPE::P * SHAPE::P : SHAPE::P) : 0;             // volumes of one face's halo slab
     constexpr int HGR = !GRID ? 1 : (SHAPE::P ? (((NT / PPOW) * (DIM - 1) + 1) * 2 * PERC * SHAPE::V + NT - 1) / NT : 12);
-    [[maybe_unused]] double hg[HGR];
+    // register slots of the decoded (full-block) path: units of GWC doubles; the generic path uses the same registers double by double
+    constexpr int GWC = (SHAPE::P && SHAPE::V % 2 == 0) ? 2 : 1;
+    constexpr int HG2 = (HGR + GWC - 1) / GWC;
+    [[maybe_unused]] double hg[GWC * HG2];
     [[maybe_unused]] double lmax = 0.0;
     const int per = H * (DIM == 3 ? P * P : P);
     const int nh = 2 * DIM * per;
@@ -231,7 +237,7 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             v = r2 % V;
         }
     };
-    [[maybe_unused]] auto gather_request = [&](long blk, int half) {
+    [[maybe_unused]] auto gather_request_any = [&](long blk, int half) {
         const long first = blk * ppb;
         const int npatch = (int)((n_patches - first < ppb) ? n_patches - first : ppb);
         const int ne = npatch * nA_pp + 2 * per * V;
@@ -244,7 +250,7 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             hg[r] = fv_grid_source<DIM>(Q, cd, pgtab + (half * ppb + pp) * 3, co, ax, P, H, V)[v];
         }
     };
-    [[maybe_unused]] auto gather_land = [&](long blk, int half) {
+    [[maybe_unused]] auto gather_land_any = [&](long blk, int half) {
         const long first = blk * ppb;
         const int npatch = (int)((n_patches - first < ppb) ? n_patches - first : ppb);
         const int ne = npatch * nA_pp + 2 * per * V;
@@ -262,6 +268,67 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             remote_elem(npatch, e, pp, hv, v);
             const int off = halo_place(pp, hv, co, ax);
             fv_lds[off + v] = fv_grid_source<DIM>(Q, cd, pgtab + (half * ppb + pp) * 3, co, ax, P, H, V)[v];
+        }
+    };
+    // FULL blocks (ppb patches): which remote states a lane fetches, where they come from inside the neighbour patch and where they land in the LDS
+    // copy does not depend on the block -- decoded ONCE per kernel into four integers per register slot (patch slot, face, offset inside the
+    // neighbour's halo-less patch, LDS offset); per block only the neighbour patch is looked up.  A unit is two doubles (one 16-byte load) where the
+    // variable count is even and the arrays are 16-byte aligned, one double otherwise.  (Decoded per element and block, the remote halos cost 0.36 of
+    // the 1.03 ms of the 2^20-patch step: profiles/r04_fv_grid.txt.)
+    // (16-byte units need 16-byte aligned arrays: otherwise every block takes the generic path)
+    const bool fastpath = GWC == 1 || ((reinterpret_cast<unsigned long long>(Q) | (cd.bstate ? reinterpret_cast<unsigned long long>(cd.bstate) : 0ull)) & 15) == 0;
+    [[maybe_unused]] int g_pp[HG2], g_face[HG2], g_src[HG2], g_lds[HG2];
+    if constexpr (GRID) {
+        const int nu = (ppb * nA_pp + 2 * per * V) / GWC;         // units of a full block
+#pragma unroll
+        for (int r = 0; r < HG2; r++) {
+            const int u0 = (int)threadIdx.x + r * NT, u = u0 < nu ? u0 : nu - 1;
+            int pp, hv, v, co[3] = {0, 0, 0}, ax;
+            remote_elem(ppb, u * GWC, pp, hv, v);
+            const int off = halo_place(pp, hv, co, ax);
+            const int side = co[ax] < H ? 0 : 1;
+            int cg = 0;
+#pragma unroll
+            for (int b = 0; b < DIM; b++) cg = cg * P + ((b == ax ? (side == 0 ? co[b] + P : co[b] - P) : co[b]) - H);
+            g_pp[r] = pp;
+            g_face[r] = ax * 2 + side;
+            g_src[r] = cg * V + v;
+            g_lds[r] = u0 < nu ? off + v : -1;
+        }
+    }
+    [[maybe_unused]] auto unit_src = [&](int r, int half) -> const double* {
+        const int* pgc = pgtab + (half * ppb + g_pp[r]) * 3;
+        const int ax = g_face[r] >> 1, side = g_face[r] & 1;
+        int pg[3] = {pgc[0], pgc[1], pgc[2]};
+        if (cd.bstate && (side == 0 ? pg[ax] == 0 : pg[ax] == cd.g[ax] - 1)) return cd.bstate + (long)g_face[r] * V + (g_src[r] % V);
+        pg[ax] += side == 0 ? -1 : 1;
+        if (pg[ax] < 0) pg[ax] += cd.g[ax];
+        if (pg[ax] >= cd.g[ax]) pg[ax] -= cd.g[ax];
+        const long np = DIM == 3 ? ((long)pg[0] * cd.g[1] + pg[1]) * cd.g[2] + pg[2] : (long)pg[0] * cd.g[1] + pg[1];
+        return Q + np * ncell * V + g_src[r];
+    };
+    [[maybe_unused]] auto gather_request = [&](long blk, int half) {
+        if (!fastpath || n_patches - blk * ppb < ppb) { gather_request_any(blk, half); return; }      // (misaligned arrays; ragged last block)
+#pragma unroll
+        for (int r = 0; r < HG2; r++) {
+            const double* src = unit_src(r, half);
+            if constexpr (GWC == 2) {
+                const v2d t2 = *reinterpret_cast<const v2d*>(src);
+                hg[2 * r] = t2.x;
+                hg[2 * r + 1] = t2.y;
+            } else {
+                hg[r] = *src;
+            }
+        }
+    };
+    [[maybe_unused]] auto gather_land = [&](long blk, int half) {
+        if (!fastpath || n_patches - blk * ppb < ppb) { gather_land_any(blk, half); return; }
+#pragma unroll
+        for (int r = 0; r < HG2; r++) {
+            if (g_lds[r] >= 0) {
+                if constexpr (GWC == 2) *reinterpret_cast<v2d*>(fv_lds + g_lds[r]) = v2d{hg[2 * r], hg[2 * r + 1]};
+                else fv_lds[g_lds[r]] = hg[r];
+            }
         }
     };
     // faces of the last axis: from the neighbour's interior in the same LDS copy (which the staging copy wrote and nobody overwrites: only halo
@@ -356,9 +423,12 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
             // grid step: the face-halo volumes of the LDS copy take the neighbours' interior states (what a halo-fill pass would have
             // written into Q beforehand; here it costs no pass -- the lines are the ones the neighbours' own workgroups read)
             if constexpr (!PERSIST) __syncthreads();             // (the in-block copies read what the staging above wrote; PERSIST: barrier above)
-            gather_local(blk, PERSIST ? half : 0);
-            gather_land(blk, PERSIST ? half : 0);
-            if constexpr (PERSIST) {
+#ifndef EXA_FV_GRID_ABL          // (development: 1 = without the in-block copies, 2 = without the remote halos, 3 = neither -- timing only, wrong results)
+#define EXA_FV_GRID_ABL 0
+#endif
+            if constexpr ((EXA_FV_GRID_ABL & 1) == 0) gather_local(blk, PERSIST ? half : 0);
+            if constexpr ((EXA_FV_GRID_ABL & 2) == 0) gather_land(blk, PERSIST ? half : 0);
+            if constexpr (PERSIST && (EXA_FV_GRID_ABL & 2) == 0) {
                 if (blk + blk_step < nblk) gather_request(blk + blk_step, half ^ 1);
             }
         }

@@ -141,7 +141,7 @@ class StatementLowering:
         ptr_width = {}                                        # Indexed argument of a call -> doubles the callee touches from there
         out_ptr = None
         for c in calls:
-            f = self._function(c, bare and c is lhs, where, dconst)
+            f = self._function(c, bare and c == lhs, where, dconst)
             for a, kind, width in zip(c.args, f["kinds"], f["widths"]):
                 if kind in ("in", "out"):
                     ptr_width[a] = max(ptr_width.get(a, 1), width)
