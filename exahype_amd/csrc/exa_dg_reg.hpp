@@ -97,12 +97,16 @@ template <int N, class PDE, int CPW = 1> struct StageAReg {
     static constexpr int NVA = NV + NA;
     static constexpr int PS2 = 2 * VS;                                // stride of a pair array
     static constexpr int SOFF = NVA * VS;                             // S_d at SOFF + d * QSZ
-    static constexpr int PIC_D = SOFF + 3 * QSZ;
+    // ncp term sets: three more arrays G_d = (D q) / h_d behind the sums -- the derive phase contracts q itself along its pencils, the node OWNER
+    // evaluates B_d(q) G_d with the state it holds in registers (one cell per workgroup: 128 KB)
+    static constexpr bool NCPV = pde_has_ncp<PDE>::value;
+    static constexpr int GOFF = SOFF + 3 * QSZ;
+    static constexpr int PIC_D = SOFF + (NCPV ? 6 : 3) * QSZ;
     static constexpr int FS = G::NN;                                  // closing phases: [array][var][node], arrays qbar | Fbar_x | Fbar_y | Fbar_z (| source)
     static constexpr int FIN_D = (pde_has_source<PDE>::value ? 5 : 4) * NV * FS;
     static constexpr int CELL_D = PIC_D > FIN_D ? PIC_D : FIN_D;      // doubles of LDS per cell in flight
     static constexpr size_t LDS_BYTES = sizeof(double) * ((size_t)CELL_D * CPW + 2 * 3 * N);   // + the one-kernel step's corrector weights
-    static constexpr bool FITS = G::NN <= NT && 2 * sizeof(double) * (size_t)CELL_D + 2048 <= 160 * 1024;
+    static constexpr bool FITS = G::NN <= NT && (NCPV ? 1 : 2) * sizeof(double) * (size_t)CELL_D + 2048 <= 160 * 1024;
     // behind the image of dg_stage_a_kernel (StageA<3, N, PDE, CPB>::IMAGE_BYTES): lane -> packed derive task of a two-level
     // step, and of iteration 0 (one level); packed = d | level slot << 2 | pencil << 3, -1 = idle
     static constexpr int TAB_INTS = 2 * NT;
@@ -128,10 +132,10 @@ __device__ inline void lds_barrier() {
 // face node (216 face nodes = 216 lanes) are requested during the previous cell's closing phases and stay in flight across its barriers
 // (which wait for LDS operations only in this variant).  Sequence of a run: A, [B o A] x (n - 1), B.
 
-// Term sets with a non-conservative product run ONE cell per workgroup at one wave per SIMD (REG_CPW_OF = 1, second launch bound 1): the ncp part
-// of the derive phase needs the six states of a pencil at once on top of the owner state, ~290 VGPRs -- at two waves per SIMD (256) that was 288
-// spilled registers and 30.5 ms per 32^3 launch of Euler-with-pressure-as-ncp, slower than the plain kernel (26.3); a lone wave has the SIMD's 512
-// registers (the allocator parks the excess in accumulation registers instead of scratch).
+// Term sets with a non-conservative product run ONE cell per workgroup at one wave per SIMD (REG_CPW_OF = 1, second launch bound 1): their three
+// gradient arrays G_d = (D q) / h_d sit in LDS behind the sums (StageAReg::GOFF; 128 KB per cell), the node owners evaluate B_d(q) G_d.
+// (First form: B_d(q_i) (D q)_i evaluated along the pencil in the derive phase -- six states at once on top of the owner state, ~290 VGPRs,
+// 25 - 30 ms per 32^3 launch of Euler-with-pressure-as-ncp against 26.3 of the plain kernel; this form: 12.2 ms, profiles/r04_xt_ncp_kernels.txt.)
 template <class PDE> constexpr int REG_CPW_OF = pde_has_ncp<PDE>::value ? 1 : EXA_REG_CPW_DEFAULT;
 template <int N, class PDE, int CPW, bool FUSE = false>
 __global__ void __launch_bounds__(256 * CPW, (pde_has_ncp<PDE>::value ? 1 : 2))
@@ -150,6 +154,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     constexpr int NV = SA::NV, NA = SA::NA, DIM = 3;
     constexpr int NN = G::NN, NF = G::NF, SL = G::SL, PX = G::PX, PY = G::PY;
     constexpr int NT = SA::NT, LS = SA::LS, VS = SA::VS, QSZ = SA::QSZ, SOFF = SA::SOFF, FS = SA::FS, NVA = SA::NVA, PS2 = SA::PS2;
+    [[maybe_unused]] constexpr int GOFF = SA::GOFF;
     constexpr int H = N / 2;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // which of the workgroup's cells in flight (wave-uniform)
@@ -311,58 +316,66 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
             }
         }
     };
-    // NCP: B_d(q_i) (D q)_i / h_d at the nodes of the pencil, row pair by row pair (even-odd form of D on q itself: the combinations
-    // q_j +- q_{N-1-j} are formed on the fly), stored where this direction's sums go -- derive_b adds its sums to them.  A pass of its own in front
-    // of the flux part, with its own loads of q (no flux scalars): the six states of the pencil are live here and only here.
-    [[maybe_unused]] auto derive_n = [&](auto dc, const Task& tk, [[maybe_unused]] const double (&Em)[NE], [[maybe_unused]] double tA, [[maybe_unused]] double tB) {
-        constexpr int DC = decltype(dc)::value;
+    // NCP: G_d = (D q) / h_d along the pencil -- the SAME even-odd contraction as for the flux, on the states themselves (no term call, no
+    // coordinates: those belong to the node owner, who evaluates B_d(q) G_d in the fold with the state it holds in registers); a pass of its
+    // own in front of the flux part, so that the registers of the two passes overlap
+    [[maybe_unused]] auto derive_g = [&](const Task& tk, [[maybe_unused]] const double (&Em)[NE]) {
         if constexpr (NCP) {
-            // (run-time direction here, DC = -1: with this part inside the per-direction branches the back-end of ROCm 7.2 stops with "illegal VGPR
-            // to SGPR copy" on the SGPR-pinned operator entries; the generated ncp members switch on the direction themselves)
-            const int dn = DC >= 0 ? DC : tk.d;
             if (tk.on && active_now) {
-                const int off = tk.off, ps = tk.ps;
-                [[maybe_unused]] const double tl = tk.ls ? tB : tA;
-                double qa[N][NV];
+                const int off = tk.off, ps = tk.ps, go = GOFF + tk.d * QSZ;
+                const double scd = tk.d == 0 ? idx0 : (tk.d == 1 ? idx1 : idx2);
+                double e[H][NV], o[H][NV];
 #pragma unroll
-                for (int j = 0; j < N; j++) ld_group(0, off + j * ps, qa[j]);
-                const double scd = dn == 0 ? idx0 : (dn == 1 ? idx1 : idx2);
+                for (int j = 0; j < H; j++) {
+                    double qa[NV], qb[NV];
+                    ld_group(0, off + j * ps, qa);
+                    ld_group(0, off + (N - 1 - j) * ps, qb);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        e[j][v] = scd * (qa[v] + qb[v]);
+                        o[j][v] = scd * (qa[v] - qb[v]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < H; i++) {
-                    double Mq[NV], Pq[NV];
+                    double M[NV], gI[NV], gM[NV];
 #pragma unroll
-                    for (int v = 0; v < NV; v++) { Mq[v] = 0.0; Pq[v] = 0.0; }
+                    for (int v = 0; v < NV; v++) M[v] = Em[H + i] * o[0][v];
+#pragma unroll
+                    for (int j = 1; j < H; j++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) EXA_FMA(M[v], Em[j * N + H + i], o[j][v]);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) gI[v] = M[v];
 #pragma unroll
                     for (int j = 0; j < H; j++)
 #pragma unroll
-                        for (int v = 0; v < NV; v++) {
-                            Mq[v] = fma(Em[j * N + H + i], qa[j][v] - qa[N - 1 - j][v], Mq[v]);
-                            Pq[v] = fma(Em[j * N + i], qa[j][v] + qa[N - 1 - j][v], Pq[v]);
-                        }
-                    double gI[NV], gM[NV];
+                        for (int v = 0; v < NV; v++) EXA_FMA(gI[v], Em[j * N + i], e[j][v]);
 #pragma unroll
-                    for (int v = 0; v < NV; v++) { gI[v] = scd * (Mq[v] + Pq[v]); gM[v] = scd * (Mq[v] - Pq[v]); }
-                    // one node at a time, each result stored before the next starts (the kernel is at its register cap: the scheduler must not
-                    // interleave the row pairs)
-                    double xj[3] = {0.0, 0.0, 0.0};
-                    {
-                        double nI[NV];
-#pragma unroll
-                        for (int v = 0; v < NV; v++) nI[v] = 0.0;
-                        if constexpr (XT) pencil_x(tk, dn, i, xj);
-                        dg_ncp<PDE>(qa[i], gI, xj, tl, dn, nI);
-                        st_group(tk.so, off + i * ps, nI);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    double nM[NV];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) nM[v] = 0.0;
-                    if constexpr (XT) pencil_x(tk, dn, N - 1 - i, xj);
-                    dg_ncp<PDE>(qa[N - 1 - i], gM, xj, tl, dn, nM);
-                    st_group(tk.so, off + (N - 1 - i) * ps, nM);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int v = 0; v < NV; v++) gM[v] = fma(2.0, M[v], -gI[v]);
+                    st_group(go, off + i * ps, gI);
+                    st_group(go, off + (N - 1 - i) * ps, gM);
                 }
             }
+        }
+    };
+    // ... and the owner's part: sum_d B_d(q) G_d at its node for level slot ls (q: the state of that level, l its index)
+    [[maybe_unused]] auto ncp_at_owner = [&](const double* qv, int ls, int l, double (&out)[NV]) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) out[v] = 0.0;
+        if constexpr (NCP) {
+            double xo[3] = {0.0, 0.0, 0.0};
+            if constexpr (XT) owner_x(xo);
+            static_for<0, DIM>([&](auto dc) {
+                constexpr int D = decltype(dc)::value;
+                double g[NV], nd[NV];
+                ld_group(GOFF + D * QSZ, o_n + ls * SL, g);
+#pragma unroll
+                for (int v = 0; v < NV; v++) nd[v] = 0.0;
+                dg_ncp<PDE>(qv, g, xo, XT ? level_t(l) : 0.0, D, nd);
+#pragma unroll
+                for (int v = 0; v < NV; v++) out[v] += nd[v];
+            });
         }
     };
     // second half: output-stationary by row pair (i, N-1-i), each pair stored as soon as it is complete -- its stores drain under the
@@ -390,13 +403,6 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 double sM[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) sM[v] = fma(2.0, M[v], -sI[v]);
-                if constexpr (NCP) {                                   // + the non-conservative part derive_a left there (same lane, same entries)
-                    double nI[NV], nM[NV];
-                    ld_group(so, off + i * ps, nI);
-                    ld_group(so, off + (N - 1 - i) * ps, nM);
-#pragma unroll
-                    for (int v = 0; v < NV; v++) { sI[v] += nI[v]; sM[v] += nM[v]; }
-                }
                 st_group(so, off + i * ps, sI);
                 st_group(so, off + (N - 1 - i) * ps, sM);
             }
@@ -407,15 +413,13 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     //  profiles/r03_reg_kernel.txt)
     using M0 = std::integral_constant<int, 0>;                       // derive: the derivative sums
     using M1 = std::integral_constant<int, 1>;                       // ... only their non-conservative part
-    // (ncp term sets keep the run-time direction: at their register pressure the three copies of the flux part measured slower, 34.6 against 26.1 ms
-    //  per 32^3 launch of Euler with its pressure gradient as an ncp)
-    constexpr bool SPLIT_DIR = !NCP && (FXT || !pde_has_dir<PDE>::value);
+    constexpr bool SPLIT_DIR = FXT || !pde_has_dir<PDE>::value;
     auto derive = [&](const Task& tk, const DirFlux<PDE>& fx, const double (&Em)[NE], double tA, double tB, auto mode) {
         // the derive stream is the long one of a step: it gets the SIMD's issue slots ahead of the co-resident wave of the other cell in
         // flight (in its fold / load / closing segment) -- 8 % of the launch (profiles/r03_reg_kernel.txt)
         __builtin_amdgcn_s_setprio(EXA_REG_PRIO);
         double e[H][NV], o[H][NV];
-        derive_n(std::integral_constant<int, -1>{}, tk, Em, tA, tB);
+        derive_g(tk, Em);
         auto front = [&](auto dc) {                                    // the direction-dependent part: term calls
             if constexpr (decltype(mode)::value == 0) derive_a(dc, tk, fx, e, o, tA, tB);
         };
@@ -661,6 +665,12 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     #pragma unroll
                     for (int v = 0; v < NV; v++) S[v] -= Sq[v];
                 }
+                if constexpr (NCP) {                                       // + sum_d B_d(q) (D q) / h_d
+                    double nd[NV];
+                    ncp_at_owner(un, 0, 0, nd);
+    #pragma unroll
+                    for (int v = 0; v < NV; v++) S[v] += nd[v];
+                }
     #pragma unroll
                 for (int l = 0; l < N; l++)
     #pragma unroll
@@ -734,6 +744,15 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                             for (int v = 0; v < NV; v++) Sx[ls][v] -= Sq[v];
                         }
                     }
+                    if constexpr (NCP) {                               // + sum_d B_d(q_l) G_d: the gradients the derive phase left, the state from registers
+#pragma unroll
+                        for (int ls = 0; ls < NL; ls++) {
+                            double nd[NV];
+                            ncp_at_owner(q[l0 + ls], ls, l0 + ls, nd);
+#pragma unroll
+                            for (int v = 0; v < NV; v++) Sx[ls][v] += nd[v];
+                        }
+                    }
 #pragma unroll
                     for (int ls = 0; ls < NL; ls++)
 #pragma unroll
@@ -757,7 +776,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         }
 
         // ---- NCP: the time-averaged non-conservative term  sum_l w_l sum_d B_d(q_l) (D q_l) / h_d  of the FINAL iterate enters u* point-wise: one more
-        // pass of the derive phase over the levels, non-conservative part only, the owners weight what arrives with w_l
+        // pass of the derive phase over the levels, gradients only, the owners evaluate the products and weight them with w_l
         [[maybe_unused]] double pw[NV];
         if constexpr (NCP) {
 #pragma unroll
@@ -775,12 +794,10 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                     sload<2>(ops_here<N>(ops_raw)->w + l0, wl);
 #pragma unroll
                     for (int ls = 0; ls < 2; ls++) {
-                        double Sx[NV], Sy[NV], Sz[NV];
-                        ld_group(SOFF, o_n + ls * SL, Sx);
-                        ld_group(SOFF + QSZ, o_n + ls * SL, Sy);
-                        ld_group(SOFF + 2 * QSZ, o_n + ls * SL, Sz);
+                        double nd[NV];
+                        ncp_at_owner(q[l0 + ls], ls, l0 + ls, nd);
 #pragma unroll
-                        for (int v = 0; v < NV; v++) pw[v] = fma(wl[ls], Sx[v] + (Sy[v] + Sz[v]), pw[v]);
+                        for (int v = 0; v < NV; v++) pw[v] = fma(wl[ls], nd[v], pw[v]);
                     }
                     if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q);
                 }
