@@ -420,9 +420,10 @@ def test_dg_full_size_conservation_cfg1_512sq(exa):
     assert np.max(np.abs(m1 - m0)[ok] / np.abs(m0)[ok]) < 1e-12 and np.all(np.abs(m1[~ok]) < 1e-9), (m0, m1)
 
 
-@pytest.mark.parametrize("N,nc", [(4, (5, 3)), (2, (4, 4)), (8, (2, 3)), (6, (7, 4)), (3, (1, 9))])
+@pytest.mark.parametrize("N,nc", [(4, (5, 3)), (2, (4, 4)), (8, (2, 3)), (6, (7, 4)), (3, (1, 9)), (4, (130, 127)), (3, (190, 130)), (8, (100, 91))])
 def test_dg_fused_single_stage_step_vs_oracle(exa, orc, N, nc):
-    """Opt-in fused single-stage 2-D step (exa_dg_step_fused: traces stay on chip) == oracle; partial tiles, tiny grids."""
+    """Opt-in fused single-stage 2-D step (exa_dg_step_fused: traces stay on chip) == oracle; partial tiles, tiny grids, and grids with more tiles
+    than workgroups fit on the chip (the persistent grid's tile loop with the next tile requested ahead; odd cell size: the 8-byte copy path)."""
     ops = _ops(N)
     u = euler_dg_state(tuple(nc) + (N, N), seed=900 + N)
     dx = [1.0 / c for c in nc]
