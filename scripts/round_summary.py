@@ -48,7 +48,8 @@ Exchange (RCCL send / recv to self, `r04_bench_cfg2_self_exchange.json`): RCCL s
 `reserve_cus` trial in the warm-up: {json.dumps(sx.get('reserve_cus_trial'))} -> {sx.get('reserve_cus_chosen')} kept.  With a HIGH-priority NCCL process-group stream
 (`r04_bench_cfg2_self_exchange_nccl_high_priority.json`) the RCCL span is 146.9 ms (done only when the interior launch retires), 0.17 ms exposed: default is normal.
 No multi-GPU run exists (no node).
-Term sets with position / time or an ncp on the tuned kernels: `r04_xt_ncp_kernels.txt` (3-D p = 5 xt: 19.3 -> 5.8-6.0 ms per 32^3 launch; p = 7 served).
+Term sets with position / time or an ncp on the tuned kernels: `r04_xt_ncp_kernels.txt` (3-D p = 5 xt: 19.3 -> 5.8-6.0 ms per 32^3 launch, ncp: 26.3 -> 12.2 ms; p = 7 served).
+cfg 1 as a persistent grid with the next tile requested ahead: built, measured, not adopted (`r04_cfg1_persistent.txt`: the kernel is bound by vector + LDS work per tile, not by latency).
 """
 open(P + "r04_summary.md", "w").write(out)
 print(out)
