@@ -5,10 +5,12 @@
 //
 // One workgroup per tile of TX x TY cells plus the ring of face neighbours (periodic wrap), all in LDS:
 //   A  load      u of the tile and its ring, AoS -> [cell][var][node]                         (coalesced)
-//   B  pencils   per (cell, direction, transverse node): fluxes at the N nodes, the four traces q/F at L/R -> face
-//                table; interior cells also the volume term (kept in registers, added direction by direction)
-//   C  faces     per (face, node): face-wide max of the eigenvalues the pencils left in a table (no shuffle, any N),
-//                Rusanov flux F* -> table; then the pencils of the interior cells apply the lift
+//   B  pencils   per (cell, direction, transverse node): fluxes at the N nodes, the four traces q/F at L/R; the L trace (the
+//                plus side of the cell's L face) -> face table, the R trace stays in registers; trace eigenvalues -> table;
+//                interior cells also the volume term (kept in registers, added direction by direction)
+//   C  faces     the pencil lane on the MINUS side of a face: face-wide max of the eigenvalues (no shuffle, any N), Rusanov
+//                flux F* from its own R trace and the plus side's table entry -> table; then the pencils of the interior
+//                cells apply the lift (F* of the R face from registers, of the L face from the table)
 //   D  store     u of the tile                                                                 (coalesced)
 // HBM traffic per cell: (1 + ring/tile) reads + 1 write of its DoF (1 920 B at p = 3 with 4 x 4 tiles before L2 hits on
 // the shared rings; 6 400 B for the two-kernel path, 3 840 B for the survey's fused ideal with traces in HBM).
@@ -41,14 +43,15 @@ template <int N, class PDE, int TX, int TY> struct FusedSingle {
     static constexpr int LCS = LX * LY - 4;                     // cell slots
     __host__ __device__ static constexpr int slot(int lc) { return lc - (lc < LY - 1 ? 1 : (lc < LX * LY - LY ? 2 : 3)); }
     static constexpr int NFX = (TX + 1) * TY, NFY = TX * (TY + 1), NFACE = NFX + NFY;
-    static constexpr int FS0 = 2 * 2 * NV * N;                  // per face: [side][field q|F][var][node]
+    // per face: [field q|F][var][node] of its PLUS side (the minus side's pencil lane keeps its own trace in registers and computes the Rusanov
+    // flux, r4: half the table -- 37 KB per workgroup at p = 3 -- and no separate face tasks)
+    static constexpr int FS0 = 2 * NV * N;
     static constexpr int FS = FS0 + ((4 - FS0 % 8) + 8) % 8;    // (stride = 4 mod 8, as the cells)
     static constexpr int LAMO = LCS * CSP + NFACE * FS;         // offset of the eigenvalue table [face][side][node]
     static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(LAMO + NFACE * 2 * N);
     static constexpr int T_INT = TX * TY * 2 * N, T_HX = 2 * TY * N, T_HY = 2 * TX * N;
     static constexpr int NT = 256;
     static_assert(T_INT + T_HX + T_HY <= NT, "one pencil task per lane");
-    static_assert(NFACE * N <= NT, "one face task per lane");
 };
 
 template <int N, class PDE, int TX, int TY>
@@ -157,10 +160,10 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
     }
 
     // ---- B: fluxes, traces, volume term
-    double vol[N][NV];
+    double vol[N][NV], qR[NV], FR[NV];                            // (R trace, then F* of the R face)
     if (p_task) {
         const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
-        double F[N][NV], q[N][NV];
+        double F[N][NV], q[N][NV], qLv[NV];
 #pragma unroll
         for (int j = 0; j < N; j++) {
             double a[nz(PDE::NAUX)];
@@ -172,30 +175,26 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
             if (p_d == 0) PDE::template flux<0>(q[j], a, F[j]);
             else PDE::template flux<1>(q[j], a, F[j]);
         }
-        double qL[NV], qR[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            double FL = 0.0, FR = 0.0;
-            qL[v] = 0.0;
+            double qL = 0.0, FL = 0.0;
             qR[v] = 0.0;
+            FR[v] = 0.0;
 #pragma unroll
             for (int j = 0; j < N; j++) {
-                qL[v] += o->phiL[j] * q[j][v];
+                qL += o->phiL[j] * q[j][v];
                 qR[v] += o->phiR[j] * q[j][v];
                 FL += o->phiL[j] * F[j][v];
-                FR += o->phiR[j] * F[j][v];
+                FR[v] += o->phiR[j] * F[j][v];
             }
+            qLv[v] = qL;
             if (fL >= 0) {                                       // this cell is the "+" side of its L face
-                FT[fL * FS + ((1 * 2 + 0) * NV + v) * N + p_t] = qL[v];
-                FT[fL * FS + ((1 * 2 + 1) * NV + v) * N + p_t] = FL;
-            }
-            if (fR >= 0) {                                       // and the "-" side of its R face
-                FT[fR * FS + ((0 * 2 + 0) * NV + v) * N + p_t] = qR[v];
-                FT[fR * FS + ((0 * 2 + 1) * NV + v) * N + p_t] = FR;
+                FT[fL * FS + (0 * NV + v) * N + p_t] = qL;
+                FT[fL * FS + (1 * NV + v) * N + p_t] = FL;
             }
         }
-        // eigenvalue of each trace state once, here (the face tasks only take the maximum)
-        if (fL >= 0) LAM[(fL * 2 + 1) * N + p_t] = PDE::maxeig_fast(qL, p_d);
+        // eigenvalue of each trace state once, here (the face phase only takes the maximum)
+        if (fL >= 0) LAM[(fL * 2 + 1) * N + p_t] = PDE::maxeig_fast(qLv, p_d);
         if (fR >= 0) LAM[(fR * 2 + 0) * N + p_t] = PDE::maxeig_fast(qR, p_d);
         if (p_int) {
             const double sc = dt * idx[p_d];
@@ -212,29 +211,31 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
     }
     __syncthreads();                                             // every pencil has read the original u, tables complete
 
-    // ---- C1: Rusanov flux per (face, node) with the face-wide max eigenvalue; F* overwrites the lane's own q- slot
-    if (tid < NFACE * N) {
-        const int f = tid / N, t = tid - f * N;
-        double* ft = FT + f * FS;
+    // ---- C1: Rusanov flux of the lane's R face (it holds the minus side) with the face-wide max eigenvalue; F* overwrites the plus side's q slot
+    // of this node (read by this lane only)
+    if (p_task && fR >= 0) {
+        double* ft = FT + fR * FS;
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 2 * N; k++) s = fmax(s, EXA_FLD(&LAM[f * 2 * N + k]));
+        for (int k = 0; k < 2 * N; k++) s = fmax(s, EXA_FLD(&LAM[fR * 2 * N + k]));
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            const double qm = EXA_FLD(&ft[((0 * 2 + 0) * NV + v) * N + t]), Fm = EXA_FLD(&ft[((0 * 2 + 1) * NV + v) * N + t]);
-            const double qp = EXA_FLD(&ft[((1 * 2 + 0) * NV + v) * N + t]), Fp = EXA_FLD(&ft[((1 * 2 + 1) * NV + v) * N + t]);
-            ft[((0 * 2 + 0) * NV + v) * N + t] = 0.5 * (Fm + Fp) - 0.5 * s * (qp - qm);
+            const double qp = EXA_FLD(&ft[(0 * NV + v) * N + p_t]), Fp = EXA_FLD(&ft[(1 * NV + v) * N + p_t]);
+            FR[v] = 0.5 * (FR[v] + Fp) - 0.5 * s * (qp - qR[v]);
+            ft[(0 * NV + v) * N + p_t] = FR[v];
         }
     }
     __syncthreads();
     // ---- C2: volume term + surface corrector, direction by direction (two pencils share every node)
+    // (r4, measured equal and not kept: the y pencils -- a row of the cell, N NV contiguous doubles in HBM -- add theirs and store the row themselves,
+    //  no copy-out phase: 0.141 against 0.139 ms per 512^2 launch, the 160-byte row stores of 64 lanes cost what the coalesced copy does)
     for (int d = 0; d < 2; d++) {
         if (p_int && p_d == d) {
             const EXA_AS4 DgOps<N>* o = ops_here<N>(ops_raw);
             const double sc = dt * idx[d];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                const double FsL = EXA_FLD(&FT[fL * FS + v * N + p_t]), FsR = EXA_FLD(&FT[fR * FS + v * N + p_t]);
+                const double FsL = EXA_FLD(&FT[fL * FS + v * N + p_t]), FsR = FR[v];
 #pragma unroll
                 for (int i = 0; i < N; i++)
                     U[p_lc * CSP + p_n0 + i * p_ns + v] = EXA_FLD(&U[p_lc * CSP + p_n0 + i * p_ns + v]) + vol[i][v] - sc * o->iw[i] * (o->phiR[i] * FsR - o->phiL[i] * FsL);
