@@ -27,7 +27,7 @@ sh = fg["shapes"]
 g4, g15 = sh["ref-4x4"], sh["limiter-15^3"]
 out = f"""# Round 4 -- every benchmarked kernel against its roof (one MI355X, final build)
 
-Source of every number: `scripts/profile_round.sh r04b` (bench lines, `rocprofv3 --kernel-trace --stats`, FETCH_SIZE / WRITE_SIZE in separate `--pmc` passes,
+Source of every number: `scripts/profile_round.sh r04c` (bench lines, `rocprofv3 --kernel-trace --stats`, FETCH_SIZE / WRITE_SIZE in separate `--pmc` passes,
 FETCH x2 per the gfx950 correction) -- files `r04_bench_*.json`, `r04_kernel_stats_*.csv`, `traffic_*.json`, `r04_traffic_fv_grid_*.json`, `stage_a_traffic.json`,
 `stage_a_pmc.json` beside this one (this page: `scripts/round_summary.py`); notes: `r04_reg_kernel.txt` (the three-cell probe), `r04_xt_ncp_kernels.txt`,
 `r04_fv_grid.txt`.  Roofs: fp64 78.6 TFLOP/s, HBM 8.0 TB/s.
