@@ -197,6 +197,143 @@ __global__ void __launch_bounds__(256 * CPW) probe(const double* __restrict__ q0
     if (s == 1.2345e300) out[tid] = s;
 }
 
+// ---- form R (round 4, late): ROLE-SPECIALISED waves, one-level steps.  A workgroup of 768 threads = 12 waves = 3 per SIMD carries two cells:
+// waves 0..3 are derive waves (two per cell: the 108 pencils of ONE level, ~110 VGPRs of task state, no iterate), waves 4..11 the node owners
+// (four per cell: iterate + accumulators, 130 VGPRs, fold + load only).  Q and the sums are double-buffered in LDS (76 KB per cell), so the derive
+// waves stream level after level while the owners fold the level before: slot s of an iteration = derive(level s) || fold(level s - 1) +
+// load(level s + 1), one barrier per slot, seven slots per iteration (the seventh -- fold of the last level, the new iterate, load of level 0 --
+// has no derive: the iteration's dependence).  The two cells run three slots apart.
+struct ImgR {
+    static constexpr int QB = NVA * SL, SB = 3 * NV * SL, SO = 2 * QB, CELL = 2 * QB + 2 * SB;
+};
+__constant__ short c_tabR[128];             // derive lane (two waves per cell) -> d | t << 2 of its pencil, -1 idle
+__device__ inline void derive_r(double* lds, int qb, int sb, int pk, double sc) {
+    if (pk < 0) return;
+    const int d = pk & 3, t = pk >> 2;
+    const int off = pbase(d, t), ps = pstride(d), qo = qb * ImgR::QB, so = ImgR::SO + sb * ImgR::SB + d * NV * SL;
+    Euler::Dir dir;
+    Euler::dir_init(dir, d, sc);
+    double e[H][NV], o[H][NV];
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        double qa[NVA], qbb[NVA], Fa[NV], Fb[NV];
+#pragma unroll
+        for (int k = 0; k < NVA; k++) { qa[k] = LD(qo + k * SL + off + j * ps); qbb[k] = LD(qo + k * SL + off + (N - 1 - j) * ps); }
+        Euler::flux_scaled_dir(qa, qa + NV, dir, Fa);
+        Euler::flux_scaled_dir(qbb, qbb + NV, dir, Fb);
+#pragma unroll
+        for (int v = 0; v < NV; v++) { e[j][v] = Fa[v] + Fb[v]; o[j][v] = Fa[v] - Fb[v]; }
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        double M[NV], sI[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) M[v] = c_E[H + i] * o[0][v];
+#pragma unroll
+        for (int j = 1; j < H; j++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) M[v] = fma(c_E[j * N + H + i], o[j][v], M[v]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) sI[v] = M[v];
+#pragma unroll
+        for (int j = 0; j < H; j++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) sI[v] = fma(c_E[j * N + i], e[j][v], sI[v]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            ST(so + v * SL + off + i * ps, sI[v]);
+            ST(so + v * SL + off + (N - 1 - i) * ps, fma(2.0, M[v], -sI[v]));
+        }
+    }
+}
+template <int L> __device__ inline void fold_r(double* lds, int sb, int node, double (&acc)[N][NV], const double (&u)[NV]) {
+    const int so = ImgR::SO + sb * ImgR::SB;
+    double S[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) S[v] = LD(so + v * SL + node) + (LD(so + (NV + v) * SL + node) + LD(so + (2 * NV + v) * SL + node));
+#pragma unroll
+    for (int lp = 0; lp < N; lp++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) acc[lp][v] = fma(c_T[L * N + lp], S[v], L == 0 ? u[v] : acc[lp][v]);
+}
+__device__ inline void load_r(double* lds, int qb, int node, const double (&qv)[NV]) {
+    double a[NA];
+    Euler::aux_fast(qv, a);
+#pragma unroll
+    for (int v = 0; v < NV; v++) ST(qb * ImgR::QB + v * SL + node, qv[v]);
+#pragma unroll
+    for (int k = 0; k < NA; k++) ST(qb * ImgR::QB + (NV + k) * SL + node, a[k]);
+}
+// OFFS: slots the second cell runs behind the first
+template <int OFFS>
+__global__ void __launch_bounds__(768) probe_r(const double* __restrict__ q0, double* __restrict__ out, int steps, double sc) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool dwave = wave < 4;
+    const int cell = dwave ? wave >> 1 : (wave - 4) >> 2;
+    double* lds = lds_all + cell * ImgR::CELL;
+    const int otid = ((wave - 4) & 3) * 64 + lane;                      // owners: lane within the cell
+    const bool owner = !dwave && otid < NN;
+    const int node = owner ? otid : 0;
+    const int pk = dwave ? c_tabR[(wave & 1) * 64 + lane] : -1;
+    // the two roles are two separate programs with the same number of barriers: in ONE loop the owner state would be live across the derive
+    // code as well (first version: 171 spilled registers)
+    if (dwave) {
+        __syncthreads();
+        for (int p = 0; p < cell * OFFS; p++) __syncthreads();
+        for (int it = 0; it < steps; it++) {
+            sfor<0, N + 1>([&](auto sc_) {
+                constexpr int S_ = decltype(sc_)::value;
+                if constexpr (S_ < N) {
+                    __builtin_amdgcn_s_setprio(1);
+                    derive_r(lds, S_ & 1, S_ & 1, pk, sc);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                __syncthreads();
+            });
+        }
+        for (int p = cell * OFFS; p < OFFS; p++) __syncthreads();
+        return;
+    }
+    double q[N][NV], acc[N][NV], u[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) u[v] = q0[v * SL + node];
+#pragma unroll
+    for (int l = 0; l < N; l++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) { q[l][v] = u[v] * (1.0 + 1e-3 * l); acc[l][v] = u[v]; }
+    if (owner) load_r(lds, 0, node, q[0]);
+    __syncthreads();
+    for (int p = 0; p < cell * OFFS; p++) __syncthreads();
+    for (int it = 0; it < steps; it++) {
+        sfor<0, N + 1>([&](auto sc_) {
+            constexpr int S_ = decltype(sc_)::value;
+            if (owner) {
+                if constexpr (S_ >= 1) fold_r<S_ - 1>(lds, (S_ - 1) & 1, node, acc, u);
+                if constexpr (S_ == N) {
+#pragma unroll
+                    for (int l = 0; l < N; l++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) q[l][v] = acc[l][v] * 1e-3 + u[v];
+                    load_r(lds, 0, node, q[0]);
+                } else if constexpr (S_ + 1 < N) {
+                    load_r(lds, (S_ + 1) & 1, node, q[S_ + 1]);
+                }
+            }
+            __syncthreads();
+        });
+    }
+    for (int p = cell * OFFS; p < OFFS; p++) __syncthreads();
+    if (blockIdx.x == 0 && wave == 4)
+        for (int k = lane; k < ImgR::SB; k += 64) out[k] = lds[ImgR::SO + k];
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < N; l++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) s += acc[l][v] + q[l][v];
+    if (s == 1.2345e300) out[threadIdx.x] = s;
+}
+
 // lane tables: form V as dg_inst.hip fill_reg_tables (simplified: groups of one direction, residues distinct where they fit); form M: 16 pencils of
 // one direction per wave task whose bank residues keep the node pairs k, k + 1 of a 32-lane group apart (greedy)
 static void tables(short* tv, short* tm) {
@@ -250,6 +387,9 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(c_T), T, sizeof(T));
     hipMemcpyToSymbol(HIP_SYMBOL(c_tabV), tv, sizeof(tv));
     hipMemcpyToSymbol(HIP_SYMBOL(c_tabM), tm, sizeof(tm));
+    short tr[128];
+    for (int k = 0; k < 128; k++) tr[k] = k < 108 ? (short)((k / NF) | (k % NF) << 2) : (short)-1;
+    hipMemcpyToSymbol(HIP_SYMBOL(c_tabR), tr, sizeof(tr));
     std::vector<double> q(NV * SL, 0.0);
     for (int n = 0; n < NN; n++) {
         const double v[5] = {1 + 0.2 * U(rng), 0.2 * U(rng), 0.2 * U(rng), 0.2 * U(rng), 2.6 + 0.3 * U(rng)};
@@ -281,6 +421,24 @@ int main(int argc, char** argv) {
         printf("%-46s %8.3f ms for %d iterations -> %7.1f ns = %6.0f cycles per (cell, level) and CU\n", name, best, steps, ns, ns * 2.4);
         return ns;
     };
+    auto run_r = [&](auto kern, const char* name) {
+        const size_t ldsb = sizeof(double) * 2 * ImgR::CELL;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kern, dim3(256), dim3(768), ldsb, 0, dq, dout, steps, 6.0);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best = std::min(best, ms);
+        }
+        if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", name); return 0.0; }
+        const double ns = 1e6 * best / ((double)steps * N * 2);
+        printf("%-46s %8.3f ms for %d iterations -> %7.1f ns = %6.0f cycles per (cell, level) and CU\n", name, best, steps, ns, ns * 2.4);
+        return ns;
+    };
     const double v2 = run(probe<0, 2>, 2, sizeof(double) * 2 * Img<2>::CELL, 2, "V: 2 cells x 2 levels per step (shipped form)");
     const double v1 = run(probe<0, 1>, 1, sizeof(double) * 1 * Img<2>::CELL, 2, "V: 1 cell alone");
     const double m3 = run(probe<1, 3>, 3, sizeof(double) * 3 * Img<1>::CELL, 1, "M: 3 cells x 1 level per step, matrix derive");
@@ -288,6 +446,10 @@ int main(int argc, char** argv) {
     const double m1 = run(probe<1, 1>, 1, sizeof(double) * 1 * Img<1>::CELL, 1, "M: 1 cell alone");
     const double n3 = run(probe<2, 3>, 3, sizeof(double) * 3 * Img<1>::CELL, 1, "M': 3 cells, fold + load in one phase");
     const double n2 = run(probe<2, 2>, 2, sizeof(double) * 2 * Img<1>::CELL, 1, "M': 2 cells");
+    const double r3 = run_r(probe_r<3>, "R: role-specialised waves, cells 3 slots apart");
+    const double r0 = run_r(probe_r<0>, "R: cells in the same slot");
+    const double r1 = run_r(probe_r<1>, "R: cells 1 slot apart");
+    printf("R3 / V2 = %.3f   R0 / V2 = %.3f   R1 / V2 = %.3f\n", r3 / v2, r0 / v2, r1 / v2);
     printf("M'3 / V2 = %.3f   [M'2 %.0f ns]\n", n3 / v2, n2);
     printf("M3 / V2 = %.3f  (below 0.92 would justify building the kernel: VERDICT r3 item 2)   [V1 %.0f, M2 %.0f, M1 %.0f ns]\n", m3 / v2, v1, m2, m1);
     return 0;
