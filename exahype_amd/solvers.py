@@ -801,7 +801,8 @@ class FVPatchGrid:
     def run(self, t_end, cfl=0.4, max_steps=1000000):
         steps = 0
         while self.time < t_end * (1 - 1e-14) and steps < max_steps:
-            dt = min(cfl * self.h / (self.dim * self.max_eigenvalue()), t_end - self.time)       # (the step's one host read)
+            lam = self.max_eigenvalue()                                                         # (the step's one host read)
+            dt = min(cfl * self.h / (self.dim * lam), t_end - self.time) if lam > 0.0 else t_end - self.time   # (nothing moves: one step to the end)
             self.step(dt)
             steps += 1
         return steps
@@ -817,7 +818,8 @@ def _dg_run(self, t_end, cfl=0.4, max_steps=1000000):
         if self.part is not None and self.part.world > 1:
             import torch.distributed as dist
             dist.all_reduce(lam, op=dist.ReduceOp.MAX)
-        dt = min(cfl * min(self.dx) / ((2 * self.N - 1) * self.dim * float(lam[0])), t_end - t)
+        lmax = float(lam[0])
+        dt = min(cfl * min(self.dx) / ((2 * self.N - 1) * self.dim * lmax), t_end - t) if lmax > 0.0 else t_end - t
         self.step(dt)
         t += dt
         steps += 1
