@@ -376,6 +376,7 @@ static void tables(short* tv, short* tm) {
 
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? atoi(argv[1]) : 1000;     // Picard iterations (6 levels each)
+    const int grid = argc > 2 ? atoi(argv[2]) : 256;       // workgroups (one per CU); fewer: does a CU run faster when the chip is not full?
     std::mt19937_64 rng(6);
     std::uniform_real_distribution<double> U(-1.0, 1.0);
     double E[H * N], T[N * N];
@@ -407,7 +408,7 @@ int main(int argc, char** argv) {
         float best = 1e30f;
         for (int rep = 0; rep < 3; rep++) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL(kern, dim3(256), dim3(256 * cpw), ldsb, 0, dq, dout, steps, 6.0);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * cpw), ldsb, 0, dq, dout, steps, 6.0);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             float ms;
@@ -427,7 +428,7 @@ int main(int argc, char** argv) {
         float best = 1e30f;
         for (int rep = 0; rep < 3; rep++) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL(kern, dim3(256), dim3(768), ldsb, 0, dq, dout, steps, 6.0);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(768), ldsb, 0, dq, dout, steps, 6.0);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             float ms;
