@@ -36,9 +36,16 @@ __host__ __device__ inline int pstride(int d) { return d == 0 ? NF : (d == 1 ? N
 template <int LV> struct Img {
     static constexpr int VS = LV * SL, SOFF = NVA * VS, QSZ = NV * VS, CELL = SOFF + 3 * QSZ;
 };
-template <int LV, int L0> __device__ inline void fold(double* lds, int node, double (&acc)[N][NV], const double (&u)[NV]) {
+template <int LV, int L0, bool GS = false> __device__ inline void fold(double* lds, int node, double (&acc)[N][NV], const double (&u)[NV], const double* gs = nullptr) {
     using I = Img<LV>;
     double S[LV][NV];
+    if constexpr (GS) {
+#pragma unroll
+        for (int ls = 0; ls < LV; ls++)
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+                S[ls][v] = gs[v * I::VS + ls * SL + node] + (gs[I::QSZ + v * I::VS + ls * SL + node] + gs[2 * I::QSZ + v * I::VS + ls * SL + node]);
+    } else
 #pragma unroll
     for (int ls = 0; ls < LV; ls++)
 #pragma unroll
@@ -69,7 +76,7 @@ template <int I_, int E_, class F> __device__ inline void sfor(F&& f) {
 }
 
 // ---- form V derive: one pencil per lane, run-time direction (exa_dg_reg.hpp derive_a / derive_b)
-__device__ inline void derive_v(double* lds, int pk, double sc) {
+template <bool GS = false> __device__ inline void derive_v(double* lds, int pk, double sc, double* gs = nullptr) {
     using I = Img<2>;
     if (pk < 0) return;
     const int d = pk & 3, ls = (pk >> 2) & 1, t = pk >> 3;
@@ -104,8 +111,13 @@ __device__ inline void derive_v(double* lds, int pk, double sc) {
             for (int v = 0; v < NV; v++) sI[v] = fma(c_E[j * N + i], e[j][v], sI[v]);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            ST(so + v * I::VS + off + i * ps, sI[v]);
-            ST(so + v * I::VS + off + (N - 1 - i) * ps, fma(2.0, M[v], -sI[v]));
+            if constexpr (GS) {
+                gs[so - I::SOFF + v * I::VS + off + i * ps] = sI[v];
+                gs[so - I::SOFF + v * I::VS + off + (N - 1 - i) * ps] = fma(2.0, M[v], -sI[v]);
+            } else {
+                ST(so + v * I::VS + off + i * ps, sI[v]);
+                ST(so + v * I::VS + off + (N - 1 - i) * ps, fma(2.0, M[v], -sI[v]));
+            }
         }
     }
 }
@@ -143,7 +155,8 @@ __device__ inline void derive_m(double* lds, int lane, int wtask, double sc0, do
 // FORM 0 = V (CPW cells of 256 threads, 2 levels per step, 2 phases), FORM 1 = M (1 level per step, 3 phases)
 template <int FORM, int CPW>
 __global__ void __launch_bounds__(256 * CPW) probe(const double* __restrict__ q0, double* __restrict__ out, int steps, double sc) {
-    constexpr int LV = FORM == 0 ? 2 : 1;                      // FORM 2: as 1 with fold + load in ONE phase (two barriers per level)
+    constexpr int LV = (FORM == 0 || FORM == 3) ? 2 : 1;       // FORM 2: as 1 with fold + load in ONE phase (two barriers per level); FORM 3: as 0, sums through global memory
+    [[maybe_unused]] double* gs = out + 4096 + ((size_t)blockIdx.x * CPW + (threadIdx.x >> 8)) * (3 * Img<2>::QSZ);
     using I = Img<LV>;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
@@ -168,13 +181,15 @@ __global__ void __launch_bounds__(256 * CPW) probe(const double* __restrict__ q0
             constexpr int L0 = decltype(sc_)::value * LV;
             __builtin_amdgcn_s_setprio(1);
             if constexpr (FORM == 0) derive_v(lds, pkV, sc);
+            else if constexpr (FORM == 3) derive_v<true>(lds, pkV, sc, gs);
             else {
                 derive_m(lds, lane, wave, sc, sc, sc);
                 derive_m(lds, lane, 4 + wave, sc, sc, sc);
             }
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();
-            if (owner) fold<LV, L0>(lds, node, acc, u);
+            if constexpr (FORM == 3) { if (owner) fold<LV, L0, true>(lds, node, acc, u, gs); }
+            else if (owner) fold<LV, L0>(lds, node, acc, u);
             if constexpr (FORM == 1) __syncthreads();                  // (FORM 1: three phases per step)
             if constexpr (L0 + LV >= N) {                              // end of an iteration: the accumulators are the new iterate
 #pragma unroll
@@ -398,7 +413,7 @@ int main(int argc, char** argv) {
     }
     double *dq, *dout;
     hipMalloc(&dq, q.size() * 8);
-    hipMalloc(&dout, 8 * 3 * NV * 2 * SL);
+    hipMalloc(&dout, 8 * (4096 + (size_t)256 * 2 * 3 * Img<2>::QSZ + 3 * NV * 2 * SL));
     hipMemcpy(dq, q.data(), q.size() * 8, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -441,6 +456,8 @@ int main(int argc, char** argv) {
         return ns;
     };
     const double v2 = run(probe<0, 2>, 2, sizeof(double) * 2 * Img<2>::CELL, 2, "V: 2 cells x 2 levels per step (shipped form)");
+    const double g2 = run(probe<3, 2>, 2, sizeof(double) * 2 * Img<2>::CELL, 2, "G: as V, the sums through global memory (L2)");
+    printf("G2 / V2 = %.3f\n", g2 / v2);
     const double v1 = run(probe<0, 1>, 1, sizeof(double) * 1 * Img<2>::CELL, 2, "V: 1 cell alone");
     const double m3 = run(probe<1, 3>, 3, sizeof(double) * 3 * Img<1>::CELL, 1, "M: 3 cells x 1 level per step, matrix derive");
     const double m2 = run(probe<1, 2>, 2, sizeof(double) * 2 * Img<1>::CELL, 1, "M: 2 cells (same code, 2 waves per SIMD)");
