@@ -303,7 +303,12 @@ class StatementLowering:
             cases[val] = {"temps": [(str(a), pr.doprint(b)) for a, b in repl], "results": [pr.doprint(e) for e in red]}
             n_out = len(exprs)
         if "out" in kinds:
-            widths[kinds.index("out")] = n_out
+            jo = kinds.index("out")
+            room = self.arrays[str(call.args[jo].base)][1]
+            if n_out > room:
+                raise LoweringRefused("%s: the body of `%s` returns %d expressions, its out-parameter `%s` holds %d entries per volume"
+                                      % (where, name, n_out, call.args[jo].base, room))
+            widths[jo] = n_out
         f = {"name": name, "kinds": kinds, "widths": widths, "params": params, "cases": cases, "returns": "void" if "out" in kinds else "double",
              "dir_param": next((p.split()[-1] for p, kd in zip(params, kinds) if kd == "dir"), None),
              "out_param": next((p.split()[-1] for p, kd in zip(params, kinds) if kd == "out"), None)}

@@ -159,6 +159,14 @@ def test_what_cannot_run_in_parallel_or_in_bounds_is_refused():
     k.directional(T[0], f(Q[0]))
     with pytest.raises(LoweringRefused, match="returns a list"):
         StatementLowering(k)
+    # a body that returns more entries than its out-parameter holds per volume would write into the next volume
+    k = KernelBuilder(dim=2, patch_size=4, halo_size=1, n_real=2, n_aux=0)
+    Q, T = k.item('Q'), k.directional_item('T')
+    f = k.function('Flux', body=lambda q, n: [q[0], q[1], q[0] * q[1]])
+    ax = k.directional_const('ax', [0, 1])
+    k.directional(f(Q[0], ax, T[0]))
+    with pytest.raises(LoweringRefused, match="returns 3 expressions.*holds 2 entries"):
+        StatementLowering(k)
     # a second item is the reference's halo-less array, addressed with `patch - 1`: out of bounds for the first patch (B-6)
     k = KernelBuilder(dim=2, patch_size=4, halo_size=1, n_real=2, n_aux=0)
     Q, C = k.item('Q'), k.item('Qcopy')
