@@ -67,8 +67,12 @@ dg_fused_single_kernel(const double* __restrict__ u_in, double* __restrict__ u_o
 
     double* LAM = lds + FU::LAMO;
     const int tid = threadIdx.x;
-    const long lb = xcd_contiguous(blockIdx.x, gridDim.x);      // neighbouring tiles (shared rings) on the same XCD's L2
-    const long tx0 = (lb / tiles_y) * TX, ty0 = (lb % tiles_y) * TY;
+    // neighbouring tiles (shared rings) on the same XCD's L2 (xcd_contiguous); 32-bit arithmetic: the grid is the tile count, and a 64-bit
+    // division is ~100 scalar instructions in front of the tile's first load
+    const unsigned nb = gridDim.x, bi = blockIdx.x, per = nb / 8u;
+    const unsigned lb = bi < per * 8u ? (bi % 8u) * per + bi / 8u : bi;
+    const unsigned ty_n = (unsigned)tiles_y, lbx = lb / ty_n;
+    const long tx0 = (long)lbx * TX, ty0 = (long)(lb - lbx * ty_n) * TY;
     const double idx[2] = {idx0, idx1};
     const bool wide = CS % 2 == 0 && CSP % 2 == 0 && ((reinterpret_cast<unsigned long long>(u_in) | reinterpret_cast<unsigned long long>(u_out)) & 15) == 0;
 
