@@ -1,23 +1,28 @@
-"""Stage B (Riemann + corrector) launch time -- development aid.  usage: quick_bench_stage_b.py N cells [reps]"""
+"""Stage B (Riemann solve + corrector) alone on a 3-D block: ms per launch and the algorithmic HBM rate (development aid).
+usage: quick_bench_stage_b.py N cells [reps]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from exahype_amd import solvers as exa
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+
+N, nc = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-s = exa.AderDgSolver(3, N, (n, n, n))
-g = torch.Generator(device="cuda"); g.manual_seed(1)
-u = torch.rand(s._u.shape, generator=g, device="cuda", dtype=torch.float64) * 0.1
-u[..., 0] += 1.0; u[..., 4] += 2.5
-s._u.copy_(u)
-dt = 1e-6
+s = exa.AderDgSolver(3, N, (nc,) * 3, pde=exa.PDE_EULER, n_vars=5)
+g = torch.Generator(device='cuda'); g.manual_seed(4)
+sh = s.u.shape[:-1]
+rho = 1 + 0.2 * torch.rand(sh, generator=g, device='cuda', dtype=torch.float64)
+s.u[..., 0] = rho
+for a in range(3): s.u[..., 1 + a] = rho * (0.4 * torch.rand(sh, generator=g, device='cuda', dtype=torch.float64) - 0.2)
+s.u[..., 4] = 2.6 + 0.5 * torch.rand(sh, generator=g, device='cuda', dtype=torch.float64)
+dt = 0.05 * s.dx[0] / (2 * N - 1) / 3 / 2.5
 s.predictor_volume(dt)
+u0 = s.u.clone()
 s.riemann_corrector(dt); torch.cuda.synchronize()
+chk = float(s.u.double().sum())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps): s.riemann_corrector(dt)
 e1.record(); torch.cuda.synchronize()
-t = e0.elapsed_time(e1) / reps
+t = e0.elapsed_time(e1) / reps * 1e-3
 w = s.work()
-print(f"stage B N={N} {n}^3: {t:.3f} ms/launch  {w['bytes_b']/t/1e6:.0f} GB/s algorithmic  finite={bool(torch.isfinite(s._u).all())}", flush=True)
+print(f"stage B N={N} {nc}^3: {t*1e3:.3f} ms per launch, {w['bytes_b']/t/1e12:.2f} TB/s algorithmic (B_B); checksum after one launch {chk:.12e}", flush=True)
