@@ -23,6 +23,34 @@
 #pragma once
 #include "exa_dg_stream.hpp"
 
+#ifndef EXA_M8_XINPLACE
+#define EXA_M8_XINPLACE 1
+#endif
+#ifndef EXA_M8_LAYOUT          // 1: r5 placement of the sums (conflict-free stores for y and z, see M8Geo below); 0: all three in the layout of Q (r3 / r4)
+#define EXA_M8_LAYOUT 0
+#endif
+#ifndef EXA_M8_PLANE           // 1: r5, a wave OWNS a plane of the cell (fixed y index): its x and z pencils are its own, two of the three barriers of a step go (M8Geo below)
+#define EXA_M8_PLANE 0
+#endif
+#if (EXA_M8_LAYOUT || EXA_M8_PLANE) && !EXA_M8_XINPLACE
+#error "EXA_M8_LAYOUT / EXA_M8_PLANE store one direction in place: they need EXA_M8_XINPLACE=1"
+#endif
+#if EXA_M8_LAYOUT && EXA_M8_PLANE
+#error "EXA_M8_LAYOUT and EXA_M8_PLANE are alternatives"
+#endif
+// order between LDS accesses of different lanes of ONE wave (the hardware completes a wave's LDS operations in order; this keeps the compiler from moving them)
+#define EXA_M8_WAVE_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#if EXA_M8_PLANE
+#define EXA_M8_SYNC_PUTS() do { } while (0)      // the first round of a step reads what the wave itself put
+#else
+#define EXA_M8_SYNC_PUTS() __syncthreads()
+#endif
+#ifdef EXA_M8_ROUND_STAMPS
+#define EXA_RSTAMP(k) EXA_STAMP(k)
+#else
+#define EXA_RSTAMP(k) do { } while (0)
+#endif
+
 namespace exa {
 
 // LDS strides: row stride 8, plane stride 70, level stride 560 -- with them the lane tables (dg_inst.hip fill_m8_tables) make every LDS
@@ -32,12 +60,46 @@ namespace exa {
 // exa_dg_stream.hpp leave the x pencils 2- to 3-way conflicted in this lane mapping; found by search over the strides that fit.)
 struct M8Geo {
     static constexpr int N = 8, NN = 512, NF = 64;
+#if EXA_M8_PLANE
+    // r5, plane ownership: wave w of the workgroup owns the 64 nodes (a, b = w, c) of the cell -- every x pencil (b, c) and z pencil (a, b) with b = w lies in
+    // its own nodes, so only the y rounds exchange data between waves.  Strides 8 / 68 / 562: the owners' nodes 4 a + c cover every bank residue exactly twice
+    // (lane = 32 (c >> 2) + ((4 a + c) & 31): conflict-free puts and sum reads); a z round (16 pencils = 8 a x 2 level slots, bases 4 a + 18 ls mod 32 = the 16
+    // even residues) reads conflict-free; an x round (8 c x 2 level slots, bases c + 18 ls, lane rows in the order 0, 2, 1, 3 of the node pairs: distance 2 x 68 = 8
+    // mod 32) keeps a 2-way conflict on 2 of 32 lanes; the y rounds take their lanes from the 2-colouring search of dg_inst.hip as before.
+    static constexpr int PY = 8, PX = 68, SL = 562;
+#else
     static constexpr int PY = 8, PX = 70, SL = 560;
+#endif
     __host__ __device__ static inline int node_off(int n) { return (n / NF) * PX + ((n / N) % N) * PY + n % N; }
     __host__ __device__ static constexpr int pstride(int d) { return d == 0 ? PX : (d == 1 ? PY : 1); }
     __host__ __device__ static inline int pbase(int d, int t) {
         const int a = t / N, b = t - a * N;
         return d == 0 ? a * PY + b : (d == 1 ? a * PX + b : a * PX + b * PY);
+    }
+    // r5 (EXA_M8_LAYOUT): where the sums go.  A 16-lane ds_write_b64 group is 16 pencils at ONE node, so a store is conflict-free iff the pencils' bases differ
+    // mod 16 doubles; a 32-lane ds_read_b64 group is 16 pencils at the nodes of two lane rows k, k + 1, conflict-free iff R and R + (node distance) * stride are
+    // disjoint mod 32 (R = the bases).  In the layout of Q both hold together only if (node distance) * stride = 16 mod 32:
+    //   y (stride 8): the lane rows take the node pairs in the order 0, 2, 1, 3 (distance 2: the matrix instruction sums over its k index, any order of the
+    //      pairs will do if the operator entries follow), a wave = the pencils (a, c) with a in {k, k + 4} -- sums IN PLACE over Q, after the barrier;
+    //   z (stride 1): impossible in the layout of Q -- its sums go to a compact array [variable][level slot][wave w'][node c][lane p] (16 consecutive doubles
+    //      per store group); a wave = the 4 x 4 block of pencils (a, b) with a >> 2, b >> 2 fixed, p = 4 (a & 3) + (b & 3);
+    //   x (stride 70): array A in the layout of Q as before (its store groups stay 2-way conflicted).
+    // The node owners read all three at their node: a 32-lane owner group = the nodes (a, b, c) of one 4 x 4 block of (a, b) and one pair c in {2 m, 2 m + 1} --
+    // 32 distinct bank residues in Q (6 a + 8 b runs over the 16 even residues, c adds 0 / 1) and 32 distinct ones in the z array (16 (c & 1) + p).
+    static constexpr int ZV = 2 * NN, ZL = NN;                        // z array: variable stride, level-slot stride
+    __host__ __device__ static constexpr int ypair(int j) { return ((j & 1) << 1) | (j >> 1); }      // lane row j -> node pair (0, 2, 1, 3)
+    static constexpr int PERM_D = EXA_M8_LAYOUT ? 1 : (EXA_M8_PLANE ? 0 : -1);                         // the direction whose rounds take the pairs in that order
+    __host__ __device__ static inline int plane_slot(int n) {        // EXA_M8_PLANE: node -> owner thread (wave = y index, lane by bank residue)
+        const int a = n / NF, b = (n / N) % N, c = n % N;
+        return b * 64 + (c >> 2) * 32 + ((4 * a + c) & 31);
+    }
+    __host__ __device__ static inline int zslot(int n) {             // node -> offset in a (variable, level slot) block of the z array
+        const int a = n / NF, b = (n / N) % N, c = n % N;
+        return (2 * (a >> 2) + (b >> 2)) * 128 + c * 16 + 4 * (a & 3) + (b & 3);
+    }
+    __host__ __device__ static inline int owner_slot(int n) {        // node -> owner lane (group * 32 + bank residue in Q)
+        const int a = n / NF, b = (n / N) % N, c = n % N;
+        return ((((a >> 2) << 3) | ((b >> 2) << 2) | (c >> 1)) << 5) | ((6 * a + 8 * b + c) & 31);
     }
 };
 
@@ -90,16 +152,33 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
     int o_n;
     {
         int* table = reinterpret_cast<int*>(lds);
+#if EXA_M8_LAYOUT
+        table[G::owner_slot(tid)] = tid;                              // (a bijection)
+#elif EXA_M8_PLANE
+        table[G::plane_slot(tid)] = tid;                              // (a bijection)
+#else
         const int n = tid, blk = n & ~255;
         const int r = G::node_off(n) & 31;
         int rank = 0;
         for (int m = blk; m < n; m++) rank += ((G::node_off(m) & 31) == r) ? 1 : 0;
         table[blk + rank * 32 + r] = n;
+#endif
         __syncthreads();
         o_n = table[tid];
         __syncthreads();
     }
     const int o_off = G::node_off(o_n);
+    [[maybe_unused]] const int o_z = G::zslot(o_n);
+    // the three directional sums of level slot ls, variable v at the owner's node
+    auto sums_at = [&](int ls, int v) -> double {
+        const int p = o_off + ls * SL + v * VS;
+#if EXA_M8_LAYOUT
+        const double sy = EXA_SLD(p), sx = EXA_SLD(p + QSZ), sz = EXA_SLD(2 * QSZ + v * G::ZV + ls * G::ZL + o_z);
+#else
+        const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
+#endif
+        return sx + (sy + sz);
+    };
     [[maybe_unused]] double xc[3] = {0.0, 0.0, 0.0};                  // low corner of the current cell
     [[maybe_unused]] double xio[3] = {0.0, 0.0, 0.0};                 // reference coordinates of the owner's node
     if constexpr (XT) {
@@ -134,6 +213,12 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
     // A operands of this lane: Ee[k][i], Eo[k][i] with i = lane & 3, k = lane >> 4 (DgOps::DEO packing: [j][i] even part, [j][H + i] odd part)
     const double aEe = static_cast<const DgOps<N>*>(ops_raw)->DEO[d_j * N + (lane & 3)];
     const double aEo = static_cast<const DgOps<N>*>(ops_raw)->DEO[d_j * N + H + (lane & 3)];
+#if EXA_M8_LAYOUT || EXA_M8_PLANE     // rounds of direction M8Geo::PERM_D: rows and columns of the two 4 x 4 blocks in the order of the node pairs 0, 2, 1, 3
+    const double aEeY = static_cast<const DgOps<N>*>(ops_raw)->DEO[G::ypair(d_j) * N + G::ypair(lane & 3)];
+    const double aEoY = static_cast<const DgOps<N>*>(ops_raw)->DEO[G::ypair(d_j) * N + H + G::ypair(lane & 3)];
+#else
+    const double aEeY = aEe, aEoY = aEo;
+#endif
 
     // one round: direction D, results to A (D = 1), B (D = 2) or into hx (D = 0)
     // tA / tB: times of the two level slots (XT); mode 0: the derivative sums, 1: only their non-conservative part (the closing pass)
@@ -145,7 +230,9 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             constexpr int ps = G::pstride(D);
             // (lane constants behind opaque copies: hoisted out of the cell loop their products with the strides live through the Picard
             // iterations and spill -- 96 B of scratch, reloaded in front of every round)
-            const int dj = opaque_v(d_j);
+            const int dj0 = opaque_v(d_j);
+            const int dj = D == G::PERM_D ? G::ypair(dj0) : dj0;                 // the node pair (dj, 7 - dj) of this lane row
+            const double oEe = D == G::PERM_D ? aEeY : aEe, oEo = D == G::PERM_D ? aEoY : aEo;
             const int na = off + dj * ps, nb = off + (N - 1 - dj) * ps;
             double qa[NV], qb[NV], aa[nz(NA)], ab[nz(NA)], Fa[NV], Fb[NV];
 #pragma unroll
@@ -180,8 +267,13 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 #pragma unroll
                     for (int v = 0; v < NV; v++) { Fa[v] *= sc; Fb[v] *= sc; }
                 } else {
+#ifdef EXA_M8_ABL_NOFLUX       // (timing ablations, never in the product: results are wrong)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) { Fa[v] = qa[v] * sc + aa[v % nz(NA)]; Fb[v] = qb[v] * sc + ab[v % nz(NA)]; }
+#else
                     PDE::template flux_scaled<D>(qa, aa, sc, Fa);
                     PDE::template flux_scaled<D>(qb, ab, sc, Fb);
+#endif
                 }
             }
             [[maybe_unused]] double na_[NV], nb_[NV];                   // B_D(q) (D q) / h_D at the lane's two nodes
@@ -189,8 +281,8 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 double ga[NV], gb[NV];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const double Pq = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, qa[v] + qb[v], 0.0, 0, 0, 0);
-                    const double Mq = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, qa[v] - qb[v], 0.0, 0, 0, 0);
+                    const double Pq = __builtin_amdgcn_mfma_f64_4x4x4f64(oEe, qa[v] + qb[v], 0.0, 0, 0, 0);
+                    const double Mq = __builtin_amdgcn_mfma_f64_4x4x4f64(oEo, qa[v] - qb[v], 0.0, 0, 0, 0);
                     ga[v] = sc * (Mq + Pq);
                     gb[v] = sc * (Mq - Pq);
                     na_[v] = 0.0;
@@ -204,8 +296,12 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 double sa = 0.0, sb = 0.0;
                 if constexpr (MODE == 0) {
                     const double e = Fa[v] + Fb[v], o = Fa[v] - Fb[v];
-                    const double Pv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEe, e, 0.0, 0, 0, 0);
-                    const double Mv = __builtin_amdgcn_mfma_f64_4x4x4f64(aEo, o, 0.0, 0, 0, 0);
+#ifdef EXA_M8_ABL_NOMFMA
+                    const double Pv = oEe * e, Mv = oEo * o;
+#else
+                    const double Pv = __builtin_amdgcn_mfma_f64_4x4x4f64(oEe, e, 0.0, 0, 0, 0);
+                    const double Mv = __builtin_amdgcn_mfma_f64_4x4x4f64(oEo, o, 0.0, 0, 0, 0);
+#endif
                     sa = Mv + Pv;
                     sb = Mv - Pv;
                 }
@@ -213,12 +309,25 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                     sa += na_[v];
                     sb += nb_[v];
                 }
-                if constexpr (D == 0) {
+                if constexpr (D == 0 && !EXA_M8_XINPLACE) {
                     hx[0][v] = sa;
                     hx[1][v] = sb;
                 } else {
+#ifdef EXA_M8_ABL_NOSTORE
+                    asm volatile("" ::"v"(sa), "v"(sb));
+#elif EXA_M8_LAYOUT
+                    if constexpr (D == 2) {                            // z: the compact array, 16 consecutive doubles per store group
+                        const int zb = 2 * QSZ + v * G::ZV + (wave >> 2) * G::ZL + (wave & 3) * 128 + (lane & 15);
+                        lds[zb + dj * 16] = sa;
+                        lds[zb + (N - 1 - dj) * 16] = sb;
+                    } else {                                           // y: over Q (in place); x: array A
+                        lds[(D == 0 ? QSZ : 0) + na + v * VS] = sa;
+                        lds[(D == 0 ? QSZ : 0) + nb + v * VS] = sb;
+                    }
+#else
                     lds[D * QSZ + na + v * VS] = sa;
                     lds[D * QSZ + nb + v * VS] = sb;
+#endif
                 }
             }
         }
@@ -230,8 +339,11 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
     using M1 = std::integral_constant<int, 1>;
     auto derive = [&](int tb, double tA, double tB, auto mode) {      // tb: 0 = steps of two levels, 1 = iteration 0 (one level)
         double hx[2][NV];
+#ifdef EXA_M8_SKEW            // (experiment: the second wave of every SIMD starts its rounds EXA_M8_SKEW x 64 cycles late, so that its LDS phases fall beside the other's arithmetic)
+        if (wave >= 4) __builtin_amdgcn_s_sleep(EXA_M8_SKEW);
+#endif
 #if EXA_M8_PIPE
-        static_assert(!XT && !NCP, "EXA_M8_PIPE: built-in term sets only");
+        static_assert(!XT && !NCP && !EXA_M8_LAYOUT, "EXA_M8_PIPE: built-in term sets, r3 layout only");
         // software-pipelined over the three rounds: the LDS loads of the next round are issued in front of the matrix instructions and the
         // stores of the current one (they read Q and the scalars, which no round writes), so their latency and the store queue overlap
         const int t_ = opaque_v(tid), dj = opaque_v(d_j);
@@ -301,12 +413,58 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         matrix(D2{}, h2, na2, nb2, e, o);
         evenodd(D0{}, r, e, o);
         matrix(D0{}, true, 0, 0, e, o);                               // x last: its sums wait in registers for the barrier
+#elif EXA_M8_XINPLACE
+        // r5: the x round runs BEHIND the barrier that ends the y and z rounds and stores its sums straight over Q -- the four lanes of an x pencil (one wave) are
+        // the only readers of the nodes they overwrite, and they have read them (in-order LDS) before their matrix instructions complete.  The separate
+        // "Q := S_x" phase (10 stores per lane with nothing beside them, 955 of the 7 800 cycles of a step in the stamp build) and the ten values held over the
+        // barrier are gone; the barrier count is the same.
+#if EXA_M8_PLANE
+        // plane ownership: z on the wave's own nodes (no barrier behind the puts, which were this wave's own: LDS operations of a wave complete in order),
+        // y between the two barriers of the step, x in place on the wave's own nodes, and the fold straight behind it
+        EXA_M8_WAVE_ORDER();
+        round(std::integral_constant<int, 2>{}, tb, hx, tA, tB, mode);
+        EXA_RSTAMP(0);
+        __syncthreads();                                              // every put of the step is done
+        EXA_RSTAMP(1);
+        round(std::integral_constant<int, 1>{}, tb, hx, tA, tB, mode);
+        EXA_RSTAMP(2);
+        __syncthreads();                                              // every y round has read Q; S_y (A) is complete
+        EXA_RSTAMP(3);
+        round(std::integral_constant<int, 0>{}, tb, hx, tA, tB, mode);
+        EXA_M8_WAVE_ORDER();
+        return;
+#endif
+        // (EXA_M8_LAYOUT: the direction in place is y, the one whose stores are conflict-free in the layout of Q; before r5's layout it was x)
+        constexpr int DL = EXA_M8_LAYOUT ? 1 : 0, DF = EXA_M8_LAYOUT ? 0 : 1;
+        round(std::integral_constant<int, DF>{}, tb, hx, tA, tB, mode);
+        EXA_RSTAMP(0);
+        round(std::integral_constant<int, 2>{}, tb, hx, tA, tB, mode);
+        EXA_RSTAMP(1);
+        __syncthreads();                                              // every read of Q by the first two rounds is done
+        EXA_RSTAMP(2);
+        round(std::integral_constant<int, DL>{}, tb, hx, tA, tB, mode);
+        EXA_RSTAMP(3);
+        __syncthreads();                                              // the three directional sums are complete
+        return;
+#else
+#ifdef EXA_M8_ROUND_STAMPS     // (stamp builds: the rounds one by one in slots 0..3 -- the iteration-0 slots then hold rounds as well)
+        round(std::integral_constant<int, 1>{}, tb, hx, tA, tB, mode);
+        EXA_STAMP(0);
+        round(std::integral_constant<int, 2>{}, tb, hx, tA, tB, mode);
+        EXA_STAMP(1);
+        round(std::integral_constant<int, 0>{}, tb, hx, tA, tB, mode);
+        EXA_STAMP(2);
+        __syncthreads();
+        EXA_STAMP(3);
 #else
         round(std::integral_constant<int, 1>{}, tb, hx, tA, tB, mode);
         round(std::integral_constant<int, 2>{}, tb, hx, tA, tB, mode);
         round(std::integral_constant<int, 0>{}, tb, hx, tA, tB, mode);      // x last: its sums wait in registers for the barrier
 #endif
+#endif
+#ifndef EXA_M8_ROUND_STAMPS
         __syncthreads();                                              // every read of Q is done; S_y (A), S_z (B) are complete
+#endif
         const int off = ltab[(tb * 3 + 0) * NT + opaque_v(tid)];
         if (off != 0xffff) {                                          // Q := S_x
             constexpr int ps = G::pstride(0);
@@ -351,7 +509,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             // ---- Picard iteration 0: the iterate is constant in time -- one level, row sums of T
             put_level(0, u);
             EXA_STAMP(0);
-            __syncthreads();
+            EXA_M8_SYNC_PUTS();
             EXA_STAMP(1);
             {
                 derive(1, 0.0, 0.0, M0{});                               // iteration 0 has its own table (one level: four waves per round)
@@ -361,11 +519,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 double S[NV], Ts[N];
                 sload<N>(step_here<N>(step_raw)->Tsdt, Ts);
     #pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    const int p = o_off + v * VS;
-                    const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
-                    S[v] = sx + (sy + sz);
-                }
+                for (int v = 0; v < NV; v++) S[v] = sums_at(0, v);
                 if constexpr (pde_has_source<PDE>::value) {
                     double Sq[NV];
                     source_at(u, 0, Sq);
@@ -388,13 +542,68 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         };
         constexpr int IT0 = XT ? 0 : 1;                                // first full iteration
         if (n_it > IT0) load_levels(std::integral_constant<int, 0>{}, q);
+#ifndef EXA_M8_DEFER
+#define EXA_M8_DEFER 1
+#endif
+#if EXA_M8_DEFER
+        // r5: the time contraction of an iteration is DEFERRED to its end.  A step only sums S_x + S_y + S_z of its two levels into registers; the
+        // FMAs acc[l'] = u - dt sum_l T[l'][l] S_l run once all levels are there (same order in l as before: bit-identical).  Live through the derive
+        // rounds of step st: the levels of q not yet in LDS (10 (3 - st) doubles) + the sums so far (10 st) = 30 doubles instead of up to 60 (iterate
+        // + all eight accumulators), which is what the register allocator spilled around (10 VGPRs, 44 B of scratch, one reload per iteration).
+        for (int it = IT0; it < n_it; it++) {
+            double Sk[N][NV];
+            [[maybe_unused]] double uu[NV];
+            static_for<0, LS>([&](auto sc_) {
+                constexpr int st = decltype(sc_)::value;
+                constexpr int l0 = 2 * st;
+                EXA_STAMP(4);
+                EXA_M8_SYNC_PUTS();
+                EXA_STAMP(5);
+                derive(0, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M0{});
+                EXA_STAMP(6);
+                if constexpr (st + 1 == LS) {                          // u for the contraction below: requested in front of the sums' loads
+#pragma unroll
+                    for (int v = 0; v < NV; v++) uu[v] = up[v];
+                }
+#pragma unroll
+                for (int ls = 0; ls < 2; ls++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) Sk[l0 + ls][v] = sums_at(ls, v);
+                if constexpr (pde_has_source<PDE>::value) {           // q_t + div F = S(q): on the iterate in the owner's registers
+#pragma unroll
+                    for (int ls = 0; ls < 2; ls++) {
+                        double Sq[NV];
+                        source_at(q[l0 + ls], l0 + ls, Sq);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) Sk[l0 + ls][v] -= Sq[v];
+                    }
+                }
+                if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q);
+                EXA_STAMP(7);
+            });
+            static_for<0, LS>([&](auto sc_) {                          // q := u - dt T S, two input levels per batch of scalar operands
+                constexpr int st = decltype(sc_)::value;
+                constexpr int l0 = 2 * st;
+                double Tm[2 * N];                                      // -dt T[l'][l0 + ls], l' fastest
+                sload<2 * N>(step_here<N>(step_raw)->TdtT + l0 * N, Tm);
+#pragma unroll
+                for (int ls = 0; ls < 2; ls++)
+#pragma unroll
+                    for (int lp = 0; lp < N; lp++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++) q[lp][v] = fma(Tm[ls * N + lp], Sk[l0 + ls][v], (st == 0 && ls == 0) ? uu[v] : q[lp][v]);
+            });
+            if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, q);
+            EXA_STAMP(4);
+        }
+#else
         for (int it = IT0; it < n_it; it++) {
             double acc[N][NV];
             static_for<0, LS>([&](auto sc_) {
                 constexpr int st = decltype(sc_)::value;
                 constexpr int l0 = 2 * st;
                 EXA_STAMP(4);
-                __syncthreads();
+                EXA_M8_SYNC_PUTS();
                 EXA_STAMP(5);
 #ifdef EXA_M8_EARLY_U
                 [[maybe_unused]] double uu[NV];
@@ -418,11 +627,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 #pragma unroll
                 for (int ls = 0; ls < 2; ls++)
 #pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        const int p = o_off + ls * SL + v * VS;
-                        const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
-                        Sx[ls][v] = sx + (sy + sz);
-                    }
+                    for (int v = 0; v < NV; v++) Sx[ls][v] = sums_at(ls, v);
                 if constexpr (pde_has_source<PDE>::value) {           // q_t + div F = S(q): on the iterate in the owner's registers
 #pragma unroll
                     for (int ls = 0; ls < 2; ls++) {
@@ -453,6 +658,8 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
                 for (int v = 0; v < NV; v++) q[l][v] = acc[l][v];
         }
 
+#endif
+
         // ---- NCP: the time-averaged non-conservative term of the FINAL iterate enters u* point-wise: one more pass of the derive rounds over the
         // levels, non-conservative part only, weighted with w_l by the owners
         [[maybe_unused]] double pw[NV];
@@ -463,18 +670,14 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             static_for<0, LS>([&](auto sc_) {
                 constexpr int st = decltype(sc_)::value;
                 constexpr int l0 = 2 * st;
-                __syncthreads();
+                EXA_M8_SYNC_PUTS();
                 derive(0, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M1{});
                 double wl[2];
                 sload<2>(ops_here<N>(ops_raw)->w + l0, wl);
 #pragma unroll
                 for (int ls = 0; ls < 2; ls++)
 #pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        const int p = o_off + ls * SL + v * VS;
-                        const double sx = EXA_SLD(p), sy = EXA_SLD(p + QSZ), sz = EXA_SLD(p + 2 * QSZ);
-                        pw[v] = fma(wl[ls], sx + (sy + sz), pw[v]);
-                    }
+                    for (int v = 0; v < NV; v++) pw[v] = fma(wl[ls], sums_at(ls, v), pw[v]);
                 if constexpr (st + 1 < LS) load_levels(std::integral_constant<int, l0 + 2>{}, q);
             });
         }
