@@ -243,6 +243,94 @@ def read_traffic(name, **match):
 
 
 # ------------------------------------------------------------------------------------------------------
+# fields shared by the sharded lines (cfg 2 / 3 and cfg 4 on N ranks)
+# ------------------------------------------------------------------------------------------------------
+def sharded_roofline(a, torch, dist, s, work, ta, world, bound, extra=None):
+    """Per-rank roofline of an N > 1 line: every rank sums its stage-A launches per step (shell boxes + interior box, events on the launching
+    stream); the SLOWEST rank's sum prices the per-GPU algorithmic flops of `exa_dg_work` -- `frac` is what one GPU of the job achieves."""
+    t = torch.tensor([ta], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allt, t)
+    else:
+        allt = [t]
+    per_rank = [float(v[0]) for v in allt]
+    slow = max(per_rank)
+    ach = work["flop_a"] / slow / 1e12
+    rf = {"kernel": s.stage_a_kernel_name(), "bound": bound, "bound_basis": "algorithmic flops per GPU (SURVEY.md 8(d)) over the slowest rank's summed "
+          "stage-A launches of a step (shell boxes + interior box)", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": ach / FP64_PEAK_TFLOPS, "frac_of_measured_fma_loop": ach / FP64_MEASURED_TFLOPS, "traffic": None,
+          "traffic_source": "not collected on N > 1 (the single-GPU line of the same kernel carries it)", "launch_ms": slow * 1e3,
+          "launch_ms_per_rank": [x * 1e3 for x in per_rank], "launches_per_step": len(s.stage_a_events) // max(1, a.steps),
+          "flop_per_launch": work["flop_a"], "scope": "per rank (slowest)"}
+    if extra:
+        rf.update(extra)
+    return rf
+
+
+def exchange_fields(a, torch, dist, s, world, local, ta, selfx, reserve_trial):
+    """exchange_ms / pack_ms / overlap_frac / exposed_exchange_ms ... of a sharded run: the trace exchange (pack + RCCL send/recv) on the comm
+    stream against the interior stage A on the compute stream, worst rank each."""
+    out = {}
+    ex, ov, xp, pk = [], [], [], []
+    for ready, c0, c1, i0, i1, p1 in s.exchange_events:
+        cs, ce, ps = ready.elapsed_time(c0), ready.elapsed_time(c1), ready.elapsed_time(p1)
+        is_, ie = ready.elapsed_time(i0), ready.elapsed_time(i1)
+        ex.append(ce - ps)                         # the RCCL send / recv group alone (start() .. finish())
+        pk.append(ps - cs)                         # the pack copies in front of it
+        ov.append(max(0.0, min(ce, ie) - max(cs, is_)) / max(ce - cs, 1e-9))
+        xp.append(max(0.0, ce - ie))               # what the exchange adds to the step: its end past the end of the interior stage A
+    mine = torch.tensor([sum(ex) / len(ex), sum(ov) / len(ov), ta * 1e3, sum(xp) / len(xp), sum(pk) / len(pk)], dtype=torch.float64,
+                        device="cuda" if a.backend == "nccl" else "cpu")
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    names = [None] * world
+    dist.all_gather_object(names, "%s:%d" % (torch.cuda.get_device_name(local), local))
+    if selfx:
+        out["rehearsal"] = "sharded step on one GPU: shell / interior boxes, packed faces, ncclSend / ncclRecv to self, stage B on ghost buffers"
+    out["rccl_ranks"] = dist.get_world_size()
+    out["backend"] = dist.get_backend()
+    out["devices"] = names
+    out["exchange_ms"] = max(float(v[0]) for v in allv)              # RCCL span only; the pack copies are `pack_ms`
+    out["pack_ms"] = max(float(v[4]) for v in allv)
+    out["high_priority_comm"] = {"comm_stream": True, "nccl_process_group_stream": bool(a.backend == "nccl" and os.environ.get("EXA_NCCL_STREAM_PRIORITY", "normal") == "high")}
+    if reserve_trial is not None:
+        out["reserve_cus_chosen"] = s.reserve_cus
+        out["reserve_cus_trial"] = {str(k): v for k, v in reserve_trial.items()}
+    out["overlap_frac"] = min(float(v[1]) for v in allv)
+    out["stage_a_ms"] = max(float(v[2]) for v in allv)
+    out["exposed_exchange_ms"] = max(float(v[3]) for v in allv)
+    return out
+
+
+def reserve_cus_trial(a, torch, dist, s, step, sync, world):
+    """CUs for RCCL's transport kernels: the interior stage A is a persistent grid that fills every CU, and a resident workgroup is not
+    preempted by a higher-priority stream.  Two untimed steps each with the grid 0 and 8 workgroups short of the chip; the faster
+    setting (max over ranks) is kept for the timed steps, both are reported."""
+    trial = {}
+    for k in (0, 8):
+        s.set_reserve_cus(k)
+        step()                                                   # (settle)
+        s.exchange_events = []
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        sync()
+        el_k = (time.perf_counter() - t0) / 2
+        xp_k = max(max(0.0, ev[0].elapsed_time(ev[2]) - ev[0].elapsed_time(ev[4])) for ev in s.exchange_events)
+        tk = torch.tensor([el_k, xp_k], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        trial[k] = {"ms_per_step": 1e3 * float(tk[0]), "exposed_exchange_ms": float(tk[1])}
+    chosen = min(trial, key=lambda k: trial[k]["ms_per_step"])
+    s.set_reserve_cus(chosen)
+    step()
+    sync()
+    return trial
+
+
+# ------------------------------------------------------------------------------------------------------
 # configurations
 # ------------------------------------------------------------------------------------------------------
 def run_cfg2(a, torch, exa, world, rank, local, pde=None):
@@ -274,29 +362,7 @@ def run_cfg2(a, torch, exa, world, rank, local, pde=None):
     sync()
     reserve_trial = None
     if sharded and not a.no_reserve_trial:
-        # CUs for RCCL's transport kernels: the interior stage A is a persistent grid that fills every CU, and a resident workgroup is not
-        # preempted by a higher-priority stream.  Two untimed steps each with the grid 0 and 8 workgroups short of the chip; the faster
-        # setting (max over ranks) is kept for the timed steps, both are reported.
-        reserve_trial = {}
-        for k in (0, 8):
-            s.set_reserve_cus(k)
-            s.step(dt)                                               # (settle)
-            s.exchange_events = []
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                s.step(dt)
-            sync()
-            el_k = (time.perf_counter() - t0) / 2
-            xp_k = max(max(0.0, ev[0].elapsed_time(ev[2]) - ev[0].elapsed_time(ev[4])) for ev in s.exchange_events)
-            tk = torch.tensor([el_k, xp_k], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-            if world > 1:
-                dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-            reserve_trial[k] = {"ms_per_step": 1e3 * float(tk[0]), "exposed_exchange_ms": float(tk[1])}
-        chosen = min(reserve_trial, key=lambda k: reserve_trial[k]["ms_per_step"])
-        s.set_reserve_cus(chosen)
-        s.step(dt)
-        sync()
+        reserve_trial = reserve_cus_trial(a, torch, dist, s, lambda: s.step(dt), sync, world)
     s.stage_a_events = []                  # stage-A launch durations: events on the stream the kernels are launched on
     if sharded:
         s.exchange_events = []
@@ -351,35 +417,10 @@ def run_cfg2(a, torch, exa, world, rank, local, pde=None):
             out["cpu_baseline"] = cpu_baseline_dg(3, N, N)
             out["cpu_reference_fv"] = cpu_reference_fv()
     if sharded:
-        # the exchange (pack + RCCL send/recv) on the comm stream against the interior stage A on the compute stream
-        ex, ov, xp, pk = [], [], [], []
-        for ready, c0, c1, i0, i1, p1 in s.exchange_events:
-            cs, ce, ps = ready.elapsed_time(c0), ready.elapsed_time(c1), ready.elapsed_time(p1)
-            is_, ie = ready.elapsed_time(i0), ready.elapsed_time(i1)
-            ex.append(ce - ps)                         # the RCCL send / recv group alone (start() .. finish())
-            pk.append(ps - cs)                         # the pack copies in front of it
-            ov.append(max(0.0, min(ce, ie) - max(cs, is_)) / max(ce - cs, 1e-9))
-            xp.append(max(0.0, ce - ie))               # what the exchange adds to the step: its end past the end of the interior stage A
-        mine = torch.tensor([sum(ex) / len(ex), sum(ov) / len(ov), ta * 1e3, sum(xp) / len(xp), sum(pk) / len(pk)], dtype=torch.float64,
-                            device="cuda" if a.backend == "nccl" else "cpu")
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        names = [None] * world
-        dist.all_gather_object(names, "%s:%d" % (torch.cuda.get_device_name(local), local))
-        if selfx:
-            out["rehearsal"] = "sharded step on one GPU: shell / interior boxes, packed faces, ncclSend / ncclRecv to self, stage B on ghost buffers"
-        out["rccl_ranks"] = dist.get_world_size()
-        out["backend"] = dist.get_backend()
-        out["devices"] = names
-        out["exchange_ms"] = max(float(v[0]) for v in allv)              # RCCL span only; the pack copies are `pack_ms`
-        out["pack_ms"] = max(float(v[4]) for v in allv)
-        out["high_priority_comm"] = {"comm_stream": True, "nccl_process_group_stream": bool(a.backend == "nccl" and os.environ.get("EXA_NCCL_STREAM_PRIORITY", "normal") == "high")}
-        if reserve_trial is not None:
-            out["reserve_cus_chosen"] = s.reserve_cus
-            out["reserve_cus_trial"] = {str(k): v for k, v in reserve_trial.items()}
-        out["overlap_frac"] = min(float(v[1]) for v in allv)
-        out["stage_a_ms"] = max(float(v[2]) for v in allv)
-        out["exposed_exchange_ms"] = max(float(v[3]) for v in allv)
+        if "roofline" not in out:                                   # N > 1: the slowest rank's stage A against the per-GPU work
+            out["roofline"] = sharded_roofline(a, torch, dist, s, work, ta, world, "fp64-valu",
+                                               {"hbm_achieved_gbs": None, "note": "fp64-compute-bound (48 FLOP/B): priced against the 78.6 TFLOP/s fp64 vector peak"})
+        out.update(exchange_fields(a, torch, dist, s, world, local, ta, selfx, reserve_trial))
     return out
 
 
@@ -425,50 +466,102 @@ def run_cfg1(a, torch, exa, local):
     return out
 
 
-def run_cfg4(a, torch, exa, local, pde=None):
-    """BASELINE configs[4], the per-GPU shape on one GPU: 3-D Euler p=7, 64^3 cells, FV subcell limiter with a Bernoulli(0.05)
-    troubled mask (seed 4): troubled cells take the 15^3 FV Rusanov patch update instead of the DG result."""
+def run_cfg4(a, torch, exa, world, rank, local, pde=None):
+    """BASELINE configs[4]: 3-D Euler p=7, 64^3 cells per GPU, FV subcell limiter with a Bernoulli(0.05) troubled mask (seed 4 + rank):
+    troubled cells take the 15^3 FV Rusanov patch update instead of the DG result.  One GPU: the per-GPU shape alone.  N > 1 (or
+    --self-exchange): the block of every rank is a shard of a Cartesian process grid -- the sharded limited step (`SubcellLimiter` on a
+    partitioned `AderDgSolver`: the trace exchange overlapped with the interior predictor as in cfg 3, plus the limiter's two small exchanges,
+    troubled flags and the subcell layers of the cells across a face from a troubled one); weak scaling, same fields as cfg 3's line."""
+    import torch.distributed as dist
+    selfx = world == 1 and a.self_exchange
+    part = exa.CartesianPartition(world, rank, 3, exchange_self=(0, 1, 2) if selfx else ()) if (world > 1 or selfx) else None
+    sharded = part is not None
+    pdims = part.pdims if part else [1, 1, 1]
+    coords = part.coords if part else [0, 0, 0]
     N, n = 8, a.cells if a.cells != 128 else 64
-    s = exa.AderDgSolver(3, N, (n,) * 3, device=local, **({} if pde is None else {"pde": pde, "n_vars": 5}))
-    lam = synthetic_state(s, [0, 0, 0], [1, 1, 1], seed=4)
+    dx = [1.0 / (n * pdims[d]) for d in range(3)]
+    kw = {} if pde is None else {"pde": pde, "n_vars": 5}
+    if sharded:
+        kw.update(part=part, backend_is_gloo=(a.backend != "nccl"))
+    s = exa.AderDgSolver(3, N, (n,) * 3, dx=dx, device=local, **kw)
+    lam = synthetic_state(s, coords, pdims, seed=4 + rank)
     dt = 0.1 * min(s.dx) / ((2 * 7 + 1) * 3 * lam)
     g = torch.Generator(device=s.dev)
-    g.manual_seed(4)
+    g.manual_seed(4 + rank)
     mask = torch.rand((n,) * 3, generator=g, device=s.dev) < 0.05
     lim = exa.SubcellLimiter(s, capacity=int(0.08 * n ** 3) + 16)
     steps, warm = a.steps, max(1, a.warmup)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     for _ in range(warm):
         cnt = lim.step(dt, mask)
-    torch.cuda.synchronize()
+    sync()
     lim.check(wait=True)
+    reserve_trial = None
+    if sharded and not a.no_reserve_trial:
+        reserve_trial = reserve_cus_trial(a, torch, dist, s, lambda: lim.step(dt, mask), sync, world)
     s.stage_a_events = []
+    if sharded:
+        s.exchange_events = []
+        lim.exchange_events = []
     t0 = time.perf_counter()
     for _ in range(steps):
         lim.step(dt, mask)
-    torch.cuda.synchronize()
+    sync()
     el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
     lim.check(wait=True)                                                   # (a step past the capacity would have kept the unlimited DG result)
     ta = sum(e0.elapsed_time(e1) for e0, e1 in s.stage_a_events) / steps * 1e-3
     work = s.work()
     dof = n ** 3 * N ** 3 * 5
-    traffic, src = read_traffic("traffic_cfg4.json", cells=n, kernel=s.stage_a_kernel_name())
-    out = {"metric": "DoF-updates/sec, 3D Euler p=7 ADER-DG + FV subcell limiter, 1 MI355X", "value": dof * steps / el, "unit": "DoF-updates/s",
-           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak",
+    out = {"metric": "DoF-updates/sec, 3D Euler p=7 ADER-DG + FV subcell limiter, %s MI355X" % ("1" if world == 1 else "1/2/4/8"),
+           "value": dof * world * steps / el, "unit": "DoF-updates/s",
+           "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[4] per-GPU shape: 3D compressible Euler, ADER-DG p=7, %d^3 cells, 8 Picard iterations + "
-                                  "volume + Riemann + corrector, FV subcell limiter (15^3 patches) on a Bernoulli(0.05) troubled mask" % n,
+           "config": {"workload": "BASELINE configs[4] per-GPU shape: 3D compressible Euler, ADER-DG p=7, %d^3 cells%s, 8 Picard iterations + "
+                                  "volume + Riemann + corrector, FV subcell limiter (15^3 patches) on a Bernoulli(0.05) troubled mask"
+                                  % (n, " per GPU (%dx%dx%d process grid)" % tuple(pdims) if sharded else ""),
                       "cells_per_gpu": n ** 3, "order": 7, "n_vars": 5, "dt": dt, "troubled_cells": int(cnt),
+                      "parallelism": "cartesian-%dx%dx%d" % tuple(pdims),
                       "term_set": "built-in exa::Euler (exa_pde.hpp)" if pde is None else "generated from SymPy expressions (pde_codegen.SympyPDE)"},
-           "finite": bool(torch.isfinite(s.u).all().item()),
-           "roofline": {"kernel": s.stage_a_kernel_name(), "bound": "fp64 (valu+mfma)", "bound_basis": "algorithmic flops (SURVEY.md 8(d)); the derivative "
-                        "contraction runs on v_mfma_f64_4x4x4_4b_f64, everything else on the vector ALU -- both pipes have the 78.6 TFLOP/s fp64 peak",
-                        "mfma_busy": 0.126, "busy_source": "profiles/r03_pmc_mfma_n8.txt (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, 32^3 cells; not measured in this run)",
-                        "hbm_measured_gbs": (traffic / ta / 1e9) if traffic else None, "achieved": work["flop_a"] / ta / 1e12,
-                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": work["flop_a"] / ta / 1e12 / FP64_PEAK_TFLOPS,
-                        "frac_of_measured_fma_loop": work["flop_a"] / ta / 1e12 / FP64_MEASURED_TFLOPS, "traffic": traffic,
-                        "traffic_source": src, "launch_ms": ta * 1e3, "flop_per_launch": work["flop_a"],
-                        "algorithmic_bytes_per_launch": work["bytes_a"]}}
-    if not a.no_cpu_baseline:
+           "finite": bool(torch.isfinite(s.u).all().item())}
+    busy, busy_src = 0.126, "profiles/r03_pmc_mfma_n8.txt"
+    pf = os.path.join(ROOT, "profiles", "m8_pmc.json")                    # SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles of the current kernel (scripts/pmc_mfma_n8.sh)
+    if os.path.exists(pf):
+        rec = json.load(open(pf))
+        if rec.get("kernel") == s.stage_a_kernel_name():
+            busy, busy_src = rec["mfma_busy"], "profiles/m8_pmc.json (%s)" % rec.get("source", "rocprofv3 --pmc")
+    m8 = {"mfma_busy": busy, "busy_source": busy_src + " (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, 32^3 cells; not measured in this run)"}
+    bound = "fp64 (valu+mfma)"
+    basis = ("algorithmic flops (SURVEY.md 8(d)); the derivative contraction runs on v_mfma_f64_4x4x4_4b_f64, everything else as vector instructions -- the "
+             "matrix instruction uses the vector ALU's fp64 multipliers (profiles/r05_valu_lds_overlap.txt: the two do not overlap), one 78.6 TFLOP/s peak for both")
+    if world == 1 and not sharded:
+        traffic, src = read_traffic("traffic_cfg4.json", cells=n, kernel=s.stage_a_kernel_name())
+        out["roofline"] = {"kernel": s.stage_a_kernel_name(), "bound": bound, "bound_basis": basis,
+                           "hbm_measured_gbs": (traffic / ta / 1e9) if traffic else None, "achieved": work["flop_a"] / ta / 1e12,
+                           "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": work["flop_a"] / ta / 1e12 / FP64_PEAK_TFLOPS,
+                           "frac_of_measured_fma_loop": work["flop_a"] / ta / 1e12 / FP64_MEASURED_TFLOPS, "traffic": traffic,
+                           "traffic_source": src, "launch_ms": ta * 1e3, "flop_per_launch": work["flop_a"],
+                           "algorithmic_bytes_per_launch": work["bytes_a"]}
+        out["roofline"].update(m8)
+    else:
+        out["roofline"] = sharded_roofline(a, torch, dist, s, work, ta, world, bound, dict(m8, bound_basis_kernel=basis))
+        out.update(exchange_fields(a, torch, dist, s, world, local, ta, selfx, reserve_trial))
+        # the limiter's own two exchanges (troubled flags, then subcell layers): stream time from the first pack to the last landing, worst rank
+        lx = [e0.elapsed_time(e1) for e0, e1 in lim.exchange_events] or [0.0]
+        t = torch.tensor([sum(lx) / len(lx)], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["limiter_exchange_ms"] = float(t.item())
+    if not a.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline_dg(3, N, N, seconds=10.0)
     return out
 
@@ -621,12 +714,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path with host-staged exchange")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--self-exchange", action="store_true",
-                    help="rehearsal only (--gpus 1, cfg2): run the SHARDED step on one GPU, the periodic wrap going through RCCL send/recv to self")
+                    help="rehearsal only (--gpus 1, cfg2 / cfg4): run the SHARDED step on one GPU, the periodic wrap going through RCCL send/recv to self")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if a.config not in ("cfg2", "cfg2_sympy"):
+        if a.config not in ("cfg2", "cfg2_sympy", "cfg4", "cfg4_sympy"):
             sys.exit("bench.py: --config %s is a single-GPU configuration" % a.config)
         spawn_ranks(a.gpus, sys.argv[1:])                      # does not return
     if a.gpus != world:
@@ -685,7 +778,7 @@ def main():
             def sympy_id():
                 return sympy_euler().register()                 # (JIT-compiled by hipcc on first use; __graft_entry__.build() prebuilds it in-tree)
             runs = (("cfg2_sympy", lambda: run_cfg2(b2, torch, exa, 1, 0, local, pde=sympy_id())), ("cfg1", lambda: run_cfg1(b, torch, exa, local)),
-                    ("cfg4", lambda: run_cfg4(b, torch, exa, local)), ("cfg4_sympy", lambda: run_cfg4(b, torch, exa, local, pde=sympy_id())),
+                    ("cfg4", lambda: run_cfg4(b, torch, exa, 1, 0, local)), ("cfg4_sympy", lambda: run_cfg4(b, torch, exa, 1, 0, local, pde=sympy_id())),
                     ("fv-ref", lambda: run_fv_ref(b, torch, exa, local)), ("fv-grid", lambda: run_fv_grid(b, torch, exa, local)))
             for name, fn in runs:
                 try:
@@ -706,13 +799,13 @@ def main():
     elif a.config == "cfg2_sympy":
         out = run_cfg2(a, torch, exa, world, rank, local, pde=sympy_euler().register())
     elif a.config == "cfg4_sympy":
-        out = run_cfg4(a, torch, exa, local, pde=sympy_euler().register())
+        out = run_cfg4(a, torch, exa, world, rank, local, pde=sympy_euler().register())
     elif a.config == "fv-grid":
         out = run_fv_grid(a, torch, exa, local)
     elif a.config == "cfg1":
         out = run_cfg1(a, torch, exa, local)
     elif a.config == "cfg4":
-        out = run_cfg4(a, torch, exa, local)
+        out = run_cfg4(a, torch, exa, world, rank, local)
     else:
         out = run_fv_ref(a, torch, exa, local)
     if rank == 0:

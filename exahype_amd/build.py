@@ -66,12 +66,23 @@ def link_atomically(cmd_without_output, target):
     """Run a link command into a temporary name and rename it into place: a reader never maps a half-written library, and a killed
     hipcc leaves no truncated file behind under the final name."""
     tmp = "%s.tmp.%d" % (target, os.getpid())
-    r = subprocess.run(cmd_without_output + ["-o", tmp], capture_output=True, text=True)
+    r = subprocess.run(cmd_without_output + ["-o", tmp], capture_output=True, text=True, env=compiler_env())
     if r.returncode != 0:
         if os.path.exists(tmp):
             os.unlink(tmp)
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     os.replace(tmp, target)
+
+
+def compiler_env():
+    """Environment for compiler children.  Under a profiler (rocprofv3 sets LD_PRELOAD / ROCP_TOOL_LIBRARIES / HSA_TOOLS_LIB; with --pmc the preloaded
+    library initialises the GPU in EVERY child) hipcc would touch the GPU and then exec clang -- the exec-after-GPU-init hop this pool forbids.  The
+    compilers need none of those variables: they are removed, so a build that happens inside a profiled run is an ordinary CPU job."""
+    env = dict(os.environ)
+    for k in list(env):
+        if k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE", "ROCPROFILER_LIBRARY_CTOR") or k.startswith(("ROCPROF", "ROCP_")):
+            del env[k]
+    return env
 
 
 def _hipcc():
@@ -108,7 +119,7 @@ def _compile(unit, verbose):
     src, stem, extra = unit
     obj = os.path.join(OBJ, stem + ".o")
     cmd = [_hipcc()] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=compiler_env())
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (stem, " ".join(cmd), r.stderr[-4000:]))
     if verbose and r.stderr.strip():
@@ -130,7 +141,7 @@ def build_variant(tag, flags, jobs=None):
         jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
         with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
             objs = list(ex.map(lambda u: _compile(u, False), UNITS))
-        r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs, capture_output=True, text=True)
+        r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs, capture_output=True, text=True, env=compiler_env())
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     finally:

@@ -254,6 +254,8 @@ int exa_fv_grid_step_device(exa_fv_plan* p, const double* Q_dev, double* QNext_d
         n *= grid[a];
     }
     if (n != p->n_patches) { set_error("exa_fv_grid_step_device: the grid has %ld patches, the plan %ld", n, p->n_patches); return EXA_ERR_INVALID; }
+    // (the kernels decode a patch's grid coordinates in 32-bit arithmetic: fv_grid_coords)
+    if (n > 0xffffffffL) { set_error("exa_fv_grid_step_device: %ld patches -- a grid holds at most 2^32 - 1", n); return EXA_ERR_INVALID; }
     if (p->H > p->P) { set_error("exa_fv_grid_step_device: halo_size %d exceeds patch_size %d (the halo would reach past the face neighbour)", p->H, p->P); return EXA_ERR_INVALID; }
     int rc = use_device(p->device);
     if (rc) return rc;

@@ -1431,15 +1431,15 @@ __global__ void dg_maxeig_kernel(const double* __restrict__ u, long nnodes, doub
 #pragma unroll
         for (int v = 0; v < NV; v++) q[v] = u[i * NV + v];
 #pragma unroll
-        for (int d = 0; d < DIM; d++) m = fmax(m, PDE::maxeig(q, d));
+        for (int d = 0; d < DIM; d++) m = nan_max(m, PDE::maxeig(q, d));
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_xor(m, o, 64));
     __shared__ double wm[16];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = fmax(m, wm[w]);
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = nan_max(m, wm[w]);
         // non-negative doubles order like their bit patterns -> integer atomic max
         atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(m));
     }

@@ -26,6 +26,11 @@
 
 namespace exa {
 
+// maximum for the CFL reductions that KEEPS a NaN (fmax drops it: a state that has blown up -- negative pressure, NaN eigenvalue -- would yield a finite
+// lambda_max and the time loop would go on silently; the NaN's bit pattern also wins the unsigned atomicMax the reductions end in)
+__device__ inline double nan_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : fmax(a, b)); }
+
+
 constexpr double GAMMA = 1.4;
 
 // array extent for NAUX cached scalars: a term set may have none (zero-length arrays are not permitted in device code)

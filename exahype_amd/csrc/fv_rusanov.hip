@@ -55,7 +55,7 @@ struct FvCellData {
 // wave-level maximum -> one atomic per wave (non-negative doubles order like their bit patterns)
 __device__ inline void fv_lam_commit(double* lam, double mx) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    for (int o = 32; o > 0; o >>= 1) mx = nan_max(mx, __shfl_xor(mx, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(lam), (unsigned long long)__double_as_longlong(mx));
 }
 
@@ -276,7 +276,10 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
     // variable count is even and the arrays are 16-byte aligned, one double otherwise.  (Decoded per element and block, the remote halos cost 0.36 of
     // the 1.03 ms of the 2^20-patch step: profiles/r04_fv_grid.txt.)
     // (16-byte units need 16-byte aligned arrays: otherwise every block takes the generic path)
-    const bool fastpath = GWC == 1 || ((reinterpret_cast<unsigned long long>(Q) | (cd.bstate ? reinterpret_cast<unsigned long long>(cd.bstate) : 0ull)) & 15) == 0;
+    // (... and run-time shapes whose full blocks hold more remote halo units than the HG2 register slots of a lane cover -- 3-D P = 6 H = 1 with 15
+    // variables has 3 240 of them, HG2 * NT = 3 072 -- take the generic path too: it has the loop for what the registers do not hold)
+    const bool fastpath = (GWC == 1 || ((reinterpret_cast<unsigned long long>(Q) | (cd.bstate ? reinterpret_cast<unsigned long long>(cd.bstate) : 0ull)) & 15) == 0)
+                          && (!GRID || (ppb * nA_pp + 2 * per * V) / GWC <= HG2 * NT);
     [[maybe_unused]] int g_pp[HG2], g_face[HG2], g_src[HG2], g_lds[HG2];
     if constexpr (GRID) {
         const int nu = (ppb * nA_pp + 2 * per * V) / GWC;         // units of a full block
@@ -607,7 +610,7 @@ fv_rusanov_kernel(double* __restrict__ Q, int P_rt, int H_rt, int m_rt, int V_rt
         if constexpr (GRID) {                                        // the next step's CFL scan: eigenvalues of the NEW state of this volume
             if (cd.lam) {
 #pragma unroll
-                for (int d = 0; d < DIM; d++) lmax = fmax(lmax, fv_eig<PDE>(nv[k], xc, cd.t + dt, d));
+                for (int d = 0; d < DIM; d++) lmax = nan_max(lmax, fv_eig<PDE>(nv[k], xc, cd.t + dt, d));
             }
         }
     }
@@ -1122,10 +1125,10 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
                     if constexpr (CACHE) {
                         double an[3];
                         PDE::fv_aux(out, an);
-                        lmax = fmax(lmax, fmax(PDE::template maxeig_fv<0>(out, an), fmax(PDE::template maxeig_fv<1>(out, an), PDE::template maxeig_fv<2>(out, an))));
+                        lmax = nan_max(lmax, nan_max(PDE::template maxeig_fv<0>(out, an), nan_max(PDE::template maxeig_fv<1>(out, an), PDE::template maxeig_fv<2>(out, an))));
                     } else {
 #pragma unroll
-                        for (int d = 0; d < 3; d++) lmax = fmax(lmax, PDE::maxeig(out, d));
+                        for (int d = 0; d < 3; d++) lmax = nan_max(lmax, PDE::maxeig(out, d));
                     }
                 }
             }
@@ -1201,15 +1204,15 @@ __global__ void fv_maxeig_kernel(const double* __restrict__ Q, int P, int H, int
             for (int a = 0; a < DIM; a++) x[a] = (centre ? centre[patch * DIM + a] : 0.0) + (co[a] - H + 0.5 - 0.5 * P) * h;
         }
 #pragma unroll
-        for (int d = 0; d < DIM; d++) mx = fmax(mx, fv_eig<PDE>(q, x, t, d));
+        for (int d = 0; d < DIM; d++) mx = nan_max(mx, fv_eig<PDE>(q, x, t, d));
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    for (int o = 32; o > 0; o >>= 1) mx = nan_max(mx, __shfl_xor(mx, o, 64));
     __shared__ double wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) mx = fmax(mx, wm[w]);
+        for (int w = 1; w < 4; w++) mx = nan_max(mx, wm[w]);
         atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(mx));
     }
 }

@@ -273,8 +273,10 @@ class SympyPDE:
                 if ti in defs[tj].free_symbols or _weighted_ops(defs[ti]) < 1:
                     continue
                 diff = sympy.expand(full(defs[tj]) - full(defs[ti]))
-                # (1.4 - 0.4 is 0.9999999999999999 in binary: coefficients within rounding of an integer are that integer)
-                diff = diff.xreplace({f: sympy.Integer(round(f)) for f in diff.atoms(sympy.Float) if abs(f - round(f)) < 1e-14})
+                # (1.4 - 0.4 is 0.9999999999999999 in binary: coefficients within rounding of a NON-ZERO integer are that integer -- a relative test: a small
+                # physical constant such as 1e-15 is a coefficient of the user's PDE, not a rounding residue, and must not be snapped to 0)
+                diff = diff.xreplace({f: sympy.Integer(round(f)) for f in diff.atoms(sympy.Float)
+                                      if round(f) != 0 and abs(f - round(f)) <= 4e-16 * abs(f)})
                 if _weighted_ops(diff) <= 1 and not (diff.free_symbols & set(defs)):
                     defs[tj] = ti + diff
                     break
@@ -567,7 +569,7 @@ struct UserPDE {
         if self.max_dim >= 3:
             units += [("dg_inst.hip", "dg3.o", ["-DEXA_DIM=3", "-DEXA_UNIT_A"] + sched), ("dg_inst.hip", "dg3b.o", ["-DEXA_DIM=3", "-DEXA_UNIT_B"])]
         procs = [(o, subprocess.Popen(common + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(d, o)],
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for src, o, extra in units]
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_build.compiler_env())) for src, o, extra in units]
         for o, p in procs:
             _, err = p.communicate()
             if p.returncode != 0:

@@ -250,7 +250,22 @@ class HIPPrinter(CodePrinter):
         rng.append({0: (0, 1), 1: (0, k.n_real), 2: (0, k.n_real + k.n_aux)}.get(span, (0, 1)))
         return rng
 
-    def _plan_text(self):
+    def _stage_a_family(self):
+        """Which stage-A kernel the library picks for (dim, order) -- the rule of `exa_dg_stage_a_kernel()` (dg_inst.hip), restated for the text that
+        exists before a plan does; compile() replaces it by the name the plan itself reports."""
+        k = self.kernel()
+        N = k.patch_size
+        if self.n_picard == 0:
+            return "dg_stage_a_single_kernel<%d,%d>" % (k.dim, N)
+        if k.dim == 3 and N == 6:
+            return "dg_stage_a_reg_kernel<6> (iterate in registers, two cells per workgroup)"
+        if k.dim == 3 and N == 8:
+            return "dg_stage_a_m8_kernel (iterate in registers, derivative contraction on v_mfma_f64_4x4x4_4b_f64)"
+        if k.dim == 3 and N == 7:
+            return "dg_stage_a_stream_kernel<7> (level-streamed)"
+        return "dg_stage_a_kernel<%d,%d>" % (k.dim, N)
+
+    def _plan_text(self, stage_a=None):
         k = self.kernel()
         S = k.patch_size + 2 * k.halo_size
         V = k.n_real + k.n_aux
@@ -261,8 +276,8 @@ class HIPPrinter(CodePrinter):
              "// chosen by  : %s" % self.pde_origin]
         if self.scheme == "aderdg":
             N = k.patch_size
-            L += ["// kernels    : dg_stage_a_kernel<%d,%d> (predictor + volume + face traces), dg_stage_b_kernel<%d,%d> (Riemann + corrector)"
-                  % (k.dim, N, k.dim, N),
+            L += ["// kernels    : %s (predictor + volume + face traces%s), dg_stage_b_kernel<%d,%d> (Riemann + corrector)"
+                  % (stage_a or self._stage_a_family(), "" if stage_a else "; exa_dg_stage_a_kernel(plan) names the launched one", k.dim, N),
                   "// C-ABI      : exa_dg_plan_create(dev, %d, %d, %d, %d, %d, {%s}, &plan); exa_dg_predictor_volume; exa_dg_riemann_corrector"
                   % (k.dim, N, k.n_real, self.pde, self.n_picard, ",".join(map(str, self.grid))),
                   "// arrays     : u[%d][%s][%d] fp64, AoS (reference layout), updated in place" % (k.n_patches, "][".join([str(N)] * k.dim), k.n_real)]
@@ -321,6 +336,7 @@ class HIPPrinter(CodePrinter):
             if self.scheme == "aderdg":
                 self._impl = solvers.AderDgSolver(k.dim, k.patch_size, self.grid, pde=self.pde, n_vars=k.n_real,
                                                   n_picard=self.n_picard, device=self.device)
+                self.code = self._plan_text(stage_a=self._impl.stage_a_kernel_name())     # the plan's own word for its stage A
             else:
                 mode = solvers.FV_FAITHFUL if self.scheme == "fv-rusanov-faithful" else solvers.FV_RUSANOV
                 self._impl = solvers.FVRusanovKernel(k.dim, k.patch_size, k.halo_size, k.n_real, k.n_aux, k.n_patches,

@@ -8,6 +8,7 @@ intent, from a Peano enclave task (`exahype/printers/CPPPrinter.py:346`).  These
 classes play that role for the HIP kernels: they own nothing numerical.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -799,29 +800,36 @@ class FVPatchGrid:
         self.time += dt
 
     def run(self, t_end, cfl=0.4, max_steps=1000000):
+        """Advance until `self.time` reaches t_end (AderDgSolver.run means the same) with the CFL step cfl * h / (dim * lambda_max); returns the number of steps.
+        A non-finite lambda_max (a state that has blown up: negative pressure gives a NaN eigenvalue) raises instead of ending the loop silently."""
         steps = 0
         while self.time < t_end * (1 - 1e-14) and steps < max_steps:
             lam = self.max_eigenvalue()                                                         # (the step's one host read)
-            dt = min(cfl * self.h / (self.dim * lam), t_end - self.time) if lam > 0.0 else t_end - self.time   # (nothing moves: one step to the end)
+            dt = _cfl_step(lam, cfl * self.h / self.dim, t_end - self.time, "FVPatchGrid.run")
             self.step(dt)
             steps += 1
         return steps
 
 
+def _cfl_step(lam, scale, left, who):
+    """dt = min(scale / lambda_max, time left); lambda_max == 0.0 exactly (nothing moves): one step to the end; NaN / inf: the run has diverged."""
+    if not math.isfinite(lam) or lam < 0.0:
+        raise FloatingPointError("%s: the largest eigenvalue is %r -- the solution has left the admissible states (diverged run)" % (who, lam))
+    return min(scale / lam, left) if lam > 0.0 else left
+
+
 def _dg_run(self, t_end, cfl=0.4, max_steps=1000000):
-    """Time loop with the CFL step dt = cfl * min(dx) / ((2p+1) * d * lambda_max); with a partition the
-    maximum eigenvalue is reduced over the ranks (the only true collective of the scheme)."""
-    torch = _torch()
-    t, steps = 0.0, 0
-    while t < t_end * (1 - 1e-14) and steps < max_steps:
+    """Advance until `self.time` reaches t_end (as FVPatchGrid.run; r4 integrated a DURATION from a local t = 0 here) with the CFL step
+    dt = cfl * min(dx) / ((2p+1) * d * lambda_max); with a partition the maximum eigenvalue is reduced over the ranks (the only true collective
+    of the scheme).  Returns the number of steps; raises on a non-finite eigenvalue."""
+    steps = 0
+    while self.time < t_end * (1 - 1e-14) and steps < max_steps:
         lam = self.max_eigenvalue()
         if self.part is not None and self.part.world > 1:
             import torch.distributed as dist
             dist.all_reduce(lam, op=dist.ReduceOp.MAX)
-        lmax = float(lam[0])
-        dt = min(cfl * min(self.dx) / ((2 * self.N - 1) * self.dim * lmax), t_end - t) if lmax > 0.0 else t_end - t
+        dt = _cfl_step(float(lam[0]), cfl * min(self.dx) / ((2 * self.N - 1) * self.dim), t_end - self.time, "AderDgSolver.run")
         self.step(dt)
-        t += dt
         steps += 1
     return steps
 
@@ -850,9 +858,14 @@ class SubcellLimiter:
         would be 51 GB).  A step with more troubled cells than that is reported by check(): construct the limiter again with a
         larger capacity (capacity=n_cells serves every mask).  Raises if the patch array does not fit the free device memory."""
         torch = _torch()
+        # the FV patch update takes ONE volume size h (the reference's generated `time_step` has no cell size at all: SURVEY.md Appendix B): a grid with
+        # different cell sizes per axis would get a silently wrong update -- refused here (and in oracle/limiter_numpy.py, which restates this glue)
+        if max(solver.dx) - min(solver.dx) > 1e-12 * max(solver.dx):
+            raise ValueError("SubcellLimiter: the FV patch update takes one volume size, the grid has dx = %s; use cells of equal size per axis" % (list(solver.dx),))
         # term sets whose terms depend on position / time: the patch update of a troubled cell gets the cell's centre and the step's start time
         self._xt = bool(solver.lib.exa_pde_flags(int(solver.pde)) & 1)
         self.s = solver
+        self.exchange_events = None       # measurement hook (bench.py): one (start, end) event pair per step around the limiter's own two exchanges
         self.Ns = 2 * solver.N - 1
         self.patch_doubles = solver.lib.exa_lim_patch_count(solver._plan)
         ncell = int(np.prod(solver.nc))
@@ -981,7 +994,13 @@ class SubcellLimiter:
         ghosts = None
         if self.hx_layer is not None:                          # every rank takes part, troubled cells or not
             nc3 = s.nc + [1] * (3 - s.dim)
+            if self.exchange_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(s.dev))
             ghosts = self._exchange_subcell_layers(m.to(torch.float64).reshape(nc3))
+            if self.exchange_events is not None:
+                e1.record(torch.cuda.current_stream(s.dev))
+                self.exchange_events.append((e0, e1))
         patches = self._patches
         check(s.lib.exa_dg_project_patches_ghost(s._plan, C.c_void_p(s.u.data_ptr()), C.c_void_p(cells.data_ptr()), cap,
                                                  C.c_void_p(patches.data_ptr()), ghosts, _stream_ptr()))

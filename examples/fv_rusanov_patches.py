@@ -1,6 +1,8 @@
 """FV Rusanov patch update through the reference's operator surface on an MI355X.
 
-The statement list below is what a user of the reference writes (`KernelBuilder` + opaque PDE-term functions); instead of printing C++
+The statement list below is the one of the reference's example (`examples/Batched_stateless.py:9-35`: copy-in, flux, eigenvalue, flux difference,
+Rusanov dissipation, copy-out) under other variable names -- it is what a user of the reference writes (`KernelBuilder` + opaque PDE-term functions) and
+what the recogniser of `HIPPrinter` has to match; instead of printing C++
 (`CPPPrinter`) or MLIR, `HIPPrinter` recognises the scheme and dispatches it to the fused HIP kernel.  Q keeps the reference's layout
 [patch][(P + 2H)^dim][n_real + n_aux] (halo included, variable fastest) and is updated in place, interior only.
 

@@ -58,6 +58,8 @@ def limited_step(u, mask, dt, dx, ops, pde, fv_update, n_it=None):
     unew = A.step(u, dt, dx, ops, pde, n_it)
     proj = apply_all_axes(P, u, dim, dim)                                  # [grid.., Ns.., m]
     S = Ns + 2
+    if max(dx[:dim]) - min(dx[:dim]) > 1e-12 * max(dx[:dim]):         # one volume size per patch update: as solvers.SubcellLimiter, refuse what would be silently wrong
+        raise ValueError("limited_step: the FV patch update takes one volume size, dx = %s" % (list(dx),))
     for idx in zip(*np.nonzero(mask)):
         patch = np.zeros((S,) * dim + (u.shape[-1],))
         core = (slice(1, -1),) * dim

@@ -3,8 +3,11 @@
 * `reference_example(...)` runs the body of one of the reference's OWN example scripts where it lies under
   /root/reference (lines exec'ed in place, nothing copied; same pattern as tests/golden/make_golden.py) against
   the KernelBuilder it is given.  Tests that need it skip where the reference tree is absent (the GPU box).
-* `rusanov_patch_update(...)` is this repo's own script for the scheme the HIP back-end recognises (own names,
-  any dim / sizes): what a user of exahype_amd writes; its expected output comes from the pinned oracle.
+* `rusanov_patch_update(...)` / `cell_data_patch_update(...)` hold the STATEMENT LISTS of the reference's examples
+  (`examples/Batched_stateless.py:9-35`, `examples/kernel-generator.py:6-45`) with other variable names and free
+  dim / sizes: the statement list is the input the HIP back-end's recogniser has to match, so it is the same
+  scheme by necessity -- the same six statements in the same order, not an independent design.  Their expected
+  output comes from the pinned oracle.
 * `builder_state(k)` is the dump the golden builder-state fixtures hold (tests/golden/make_golden.py).
 """
 import os

@@ -56,6 +56,32 @@ def test_self_launched_ranks_share_one_gpu_over_gloo(gpus):
 
 
 @pytest.mark.gpu
+def test_cfg4_on_two_ranks_and_rooflines_on_sharded_lines():
+    """BASELINE configs[4] is an 8-GPU configuration: `--config cfg4 --gpus N` runs the SHARDED limited step (SubcellLimiter on a partitioned
+    AderDgSolver: trace exchange + the limiter's flag and subcell-layer exchanges) with the fields of cfg 3's line, and every N > 1 line carries a
+    per-rank roofline (the slowest rank's summed stage-A launches against the per-GPU work)."""
+    r = subprocess.run([sys.executable, BENCH, "--config", "cfg4", "--gpus", "2", "--backend", "gloo", "--share-gpu", "--cells", "4", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["finite"] and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "cartesian-2x1x1" and "limiter" in out["config"]["workload"]
+    assert out["exchange_ms"] > 0 and out["pack_ms"] >= 0 and 0.0 <= out["overlap_frac"] <= 1.0 and out["limiter_exchange_ms"] > 0
+    rf = out["roofline"]
+    assert "m8" in rf["kernel"] and rf["scope"] == "per rank (slowest)" and len(rf["launch_ms_per_rank"]) == 2
+    assert rf["frac"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_per_step"] >= 2
+    # cfg 3's sharded line: the same roofline object
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--share-gpu", "--cells", "6", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-reserve-trial"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    rf = out["roofline"]
+    assert rf["bound"] == "fp64-valu" and rf["scope"] == "per rank (slowest)" and rf["frac"] > 0 and len(rf["launch_ms_per_rank"]) == 2
+
+
+@pytest.mark.gpu
 def test_single_gpu_line_has_roofline_and_config_variants():
     r = subprocess.run([sys.executable, BENCH, "--cells", "16", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=_env(),
                        capture_output=True, text=True, timeout=900)

@@ -179,6 +179,8 @@ def _grid_state(grid, P, V, seed, dim):
     (3, (2, 1, 3), 5, 2, 1, "rusanov", True),       # 3-D, two halo layers, 125 volumes per patch (two patches per block)
     (2, (3, 2), 16, 1, 0, "rusanov", False),        # one patch per 256-thread workgroup, staged
     (2, (2, 2), 24, 1, 3, "faithful", True),        # one patch per 1024-thread workgroup, staged
+    (3, (2, 2, 2), 6, 1, 10, "rusanov", False),     # staged, 3 240 remote halo units per block > the 3 072 the decoded path's registers cover (r4 advice)
+    (3, (2, 2, 1), 6, 2, 3, "rusanov", True),       # ... 3 456 units (two halo layers, 8 variables)
 ])
 def test_grid_step_equals_halo_fill_plus_patch_update(dim, grid, P, H, n_aux, mode, dirichlet):
     """exa_fv_grid_step_device (halo-less arrays; the states beyond a patch face taken from the neighbours inside the launch) is BIT-equal to

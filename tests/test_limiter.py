@@ -31,6 +31,27 @@ def _fv(dim, nv, pde):
     return update
 
 
+def test_limited_step_refuses_cells_of_unequal_size():
+    """The FV patch update takes ONE volume size (solvers.SubcellLimiter passes dx / N_s): a grid with dx[0] != dx[1] would get a silently wrong
+    FV update -- the oracle's restatement of the glue refuses it, and so does the product (GPU test below)."""
+    N, nc = 3, (2, 2)
+    u = euler_dg_state(nc + (N, N), seed=3)
+    mask = np.zeros(nc, bool)
+    mask[0, 0] = True
+    with pytest.raises(ValueError, match="one volume size"):
+        limited_step(u, mask, 1e-3, [0.5, 0.4], operators(N), A.Euler(), _fv(2, 5, oracle.PDE_EULER))
+    limited_step(u, mask, 1e-3, [0.5, 0.5], operators(N), A.Euler(), _fv(2, 5, oracle.PDE_EULER))
+
+
+@pytest.mark.gpu
+def test_subcell_limiter_refuses_cells_of_unequal_size():
+    from exahype_amd import solvers as exa
+    s = exa.AderDgSolver(2, 3, (2, 2), dx=[0.5, 0.4])
+    with pytest.raises(ValueError, match="one volume size"):
+        exa.SubcellLimiter(s)
+    exa.SubcellLimiter(exa.AderDgSolver(2, 3, (2, 2), dx=[0.5, 0.5]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim,N,nc", [(2, 4, (4, 3)), (3, 3, (2, 2, 3)), (2, 2, (3, 3)),
                                        (3, 8, (2, 1, 2)),        # cfg 4's order: level-streamed stage A + 17^3 slab FV update + reconstruction

@@ -153,7 +153,12 @@ def test_hip_printer_aderdg_hint_and_file(tmp_path):
     k = KernelBuilder(3, 6, 0, 5, 0, n_patches=8)
     k.item('u')
     p = HIPPrinter(k, function_name="ader_step", scheme="aderdg", pde="euler")
-    assert p.grid == (2, 2, 2) and p.functionName() == "ader_step" and "dg_stage_a_kernel<3,6>" in p.code
+    # the plan text names the kernel family the library picks for (3-D, N = 6), not the generic dg_stage_a_kernel (r4 review); compile() swaps in
+    # the plan's own exa_dg_stage_a_kernel() string (tests/test_examples.py runs that on the GPU)
+    assert p.grid == (2, 2, 2) and p.functionName() == "ader_step" and "dg_stage_a_reg_kernel<6>" in p.code and "exa_dg_stage_a_kernel(plan)" in p.code
+    k4 = KernelBuilder(2, 4, 0, 5, 0, n_patches=4)
+    k4.item('u')
+    assert "dg_stage_a_kernel<2,4>" in HIPPrinter(k4, scheme="aderdg", pde="euler").code
     p.file(str(tmp_path / "plan.txt"))
     assert open(tmp_path / "plan.txt").read() == p.code
     with pytest.raises(ValueError):
