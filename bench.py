@@ -479,7 +479,7 @@ def run_cfg4(a, torch, exa, world, rank, local, pde=None):
     pdims = part.pdims if part else [1, 1, 1]
     coords = part.coords if part else [0, 0, 0]
     N, n = 8, a.cells if a.cells != 128 else 64
-    dx = [1.0 / (n * pdims[d]) for d in range(3)]
+    dx = [1.0 / (n * max(pdims))] * 3                      # cells of one size in every direction (the FV patch update has one volume size): a box, not a cube, on uneven process grids
     kw = {} if pde is None else {"pde": pde, "n_vars": 5}
     if sharded:
         kw.update(part=part, backend_is_gloo=(a.backend != "nccl"))

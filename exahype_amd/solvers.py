@@ -858,10 +858,6 @@ class SubcellLimiter:
         would be 51 GB).  A step with more troubled cells than that is reported by check(): construct the limiter again with a
         larger capacity (capacity=n_cells serves every mask).  Raises if the patch array does not fit the free device memory."""
         torch = _torch()
-        # the FV patch update takes ONE volume size h (the reference's generated `time_step` has no cell size at all: SURVEY.md Appendix B): a grid with
-        # different cell sizes per axis would get a silently wrong update -- refused here (and in oracle/limiter_numpy.py, which restates this glue)
-        if max(solver.dx) - min(solver.dx) > 1e-12 * max(solver.dx):
-            raise ValueError("SubcellLimiter: the FV patch update takes one volume size, the grid has dx = %s; use cells of equal size per axis" % (list(solver.dx),))
         # term sets whose terms depend on position / time: the patch update of a troubled cell gets the cell's centre and the step's start time
         self._xt = bool(solver.lib.exa_pde_flags(int(solver.pde)) & 1)
         self.s = solver
@@ -974,6 +970,10 @@ class SubcellLimiter:
         `capacity` cannot be served: `self.overflow` (0-dim CUDA bool) says so -- see check()."""
         torch = _torch()
         s = self.s
+        # the FV patch update takes ONE volume size h (the reference's generated `time_step` has no cell size at all: SURVEY.md Appendix B): a grid with
+        # different cell sizes per axis would get a silently wrong update -- refused (as in oracle/limiter_numpy.py, which restates this glue)
+        if max(s.dx) - min(s.dx) > 1e-12 * max(s.dx):
+            raise ValueError("SubcellLimiter.step: the FV patch update takes one volume size, the grid has dx = %s; use cells of equal size per axis" % (list(s.dx),))
         self.check()                                           # a COMPLETED earlier step past the capacity raises here (no synchronisation)
         if isinstance(mask, torch.Tensor):
             m = mask.to(device=s.dev, dtype=torch.bool)

@@ -46,10 +46,12 @@ def test_limited_step_refuses_cells_of_unequal_size():
 @pytest.mark.gpu
 def test_subcell_limiter_refuses_cells_of_unequal_size():
     from exahype_amd import solvers as exa
-    s = exa.AderDgSolver(2, 3, (2, 2), dx=[0.5, 0.4])
+    import torch
+    mask = torch.zeros((2, 2), dtype=torch.bool, device="cuda")
+    lim = exa.SubcellLimiter(exa.AderDgSolver(2, 3, (2, 2), dx=[0.5, 0.4]))      # (projection / reconstruction alone do not depend on the cell size)
     with pytest.raises(ValueError, match="one volume size"):
-        exa.SubcellLimiter(s)
-    exa.SubcellLimiter(exa.AderDgSolver(2, 3, (2, 2), dx=[0.5, 0.5]))
+        lim.step(1e-3, mask)
+    exa.SubcellLimiter(exa.AderDgSolver(2, 3, (2, 2), dx=[0.5, 0.5])).step(1e-3, mask)
 
 
 @pytest.mark.gpu

@@ -894,7 +894,7 @@ def test_limiter_hands_cell_centres_and_time_to_a_position_dependent_system():
     p = variable_coefficient_system(max_dim=2)
     pid = p.register()
     dim, N, nc = 2, 3, (4, 3)
-    dx, origin, t0, dt = [0.3, 0.4], [0.2, -0.4], 0.3, 2e-3
+    dx, origin, t0, dt = [0.3, 0.3], [0.2, -0.4], 0.3, 2e-3
     rng = np.random.default_rng(12)
     u0 = 1.0 + 0.3 * rng.random(nc + (N, N, 2))
     mask = np.zeros(nc, dtype=bool)
