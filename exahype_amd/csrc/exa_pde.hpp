@@ -257,7 +257,11 @@ struct Euler {
         const double irho = 1.0 / fabs(q[0]);
         const double p = (GAMMA - 1) * (q[4] - 0.5 * irho * (q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
         const double c = sqrt(GAMMA * fabs(p) * irho);
+#ifdef EXA_EULER_EIG_SELECT      // (r5 experiment: selects instead of the run-time index)
+        const double un = (d == 0 ? q[1] : (d == 1 ? q[2] : q[3])) * irho;
+#else
         const double un = q[d + 1] * irho;
+#endif
         return fmax(fabs(un - c), fabs(un + c));
     }
     __device__ static inline double maxeig_fast(const double* q, int d) {

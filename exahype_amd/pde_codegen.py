@@ -16,6 +16,7 @@ libexahype_hip.so (`exa_register_pde`) and returns the pde id.
 """
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -193,6 +194,59 @@ class SympyPDE:
         lines += ["%s%s = %s;" % (indent, t, pr.doprint(e)) for t, e in zip(targets, red)]
         return "\n".join(lines)
 
+    def _eig_block(self, exprs_by_dir, indent, fast=False):
+        """Body of an eigenvalue member with a run-time, per-LANE normal `d` (the Riemann kernels pack tasks of all faces into a wave): ONE straight-line
+        block -- what the directions share is computed once (common-subexpression pass over all of them) -- and, where the directions' expressions have the
+        same shape and differ only in leaves (Euler: |q[1 + d] / rho| + c), the differing leaves are picked by selects in FRONT of the arithmetic, so the
+        block costs what one direction costs; otherwise every direction is evaluated and the result picked.  (A `switch (d)` ran each direction's
+        divisions and square root in turn under masks: r4, +12 % on stage B, an HBM-bound kernel.)"""
+        md = len(exprs_by_dir)
+        pr = _DevicePrinter(fast)
+        subs = {s: sympy.Symbol("q[%d]" % i) for i, s in enumerate(self.q)}
+        subs.update({s: sympy.Symbol("x[%d]" % i) for i, s in enumerate(self.x)})
+        exprs = [sympy.sympify(e).xreplace(subs) for e in exprs_by_dir]
+        if fast:
+            exprs = [_fast_forms(e) for e in exprs]
+        repl, red = sympy.cse(exprs, symbols=sympy.numbered_symbols("t_"))
+        lines = ["%sconst double %s = %s;" % (indent, pr.doprint(a), pr.doprint(b)) for a, b in repl]
+        pick = lambda names: "".join("d == %d ? %s : (" % (d, n) for d, n in enumerate(names[:-1])) + names[-1] + ")" * (len(names) - 1)
+        sels = []
+
+        def unify(es):
+            if all(e == es[0] for e in es):
+                return es[0]
+            if all(e.is_Atom for e in es):
+                sym = sympy.Symbol("s_%d" % len(sels))
+                sels.append((sym, list(es)))
+                return sym
+            if any(e.is_Atom for e in es) or len({(e.func, len(e.args)) for e in es}) != 1:
+                raise ValueError("shapes differ")
+            return es[0].func(*[unify([e.args[k] for e in es]) for k in range(len(es[0].args))])
+        try:
+            tmpl = unify(list(red)) if md > 1 else red[0]
+            ok = all(tmpl.xreplace({sym: leaves[d] for sym, leaves in sels}) == red[d] for d in range(md))      # (Add / Mul may have re-ordered: check)
+        except ValueError:
+            ok = False
+        def leaf_select(leaves):
+            # leaves that are entries of the state: a run-time INDEX (q[d + 1]) instead of a select of doubles -- in the Riemann kernel of 3-D p = 5 the
+            # select form costs 6 - 8 VGPRs and with them the eighth resident wave per SIMD (16.5 against 15.7 ms per 128^3 launch, r5)
+            m = [re.fullmatch(r"q\[(\d+)\]", str(l)) for l in leaves]
+            if all(m) and len(leaves) > 1:
+                idx = [int(x.group(1)) for x in m]
+                step = idx[1] - idx[0]
+                if all(idx[d] == idx[0] + d * step for d in range(len(idx))) and step != 0:
+                    return "q[%d + %s]" % (idx[0], "d" if step == 1 else "%d * d" % step)
+                return "q[%s]" % pick([str(i) for i in idx])
+            return pick([pr.doprint(l) for l in leaves])
+        if ok:
+            lines += ["%sconst double %s = %s;" % (indent, sym, leaf_select(leaves)) for sym, leaves in sels]
+            lines.append("%sconst double lam = %s;" % (indent, pr.doprint(tmpl)))
+        else:
+            lines += ["%sconst double lam%d = %s;" % (indent, d, pr.doprint(e)) for d, e in enumerate(red)]
+            lines.append("%sconst double lam = %s;" % (indent, pick(["lam%d" % d for d in range(md)])))
+        lines.append("%sreturn d < %d ? lam : 0.0;" % (indent, md))
+        return "\n".join(lines)
+
     @staticmethod
     def _block_ops(exprs):
         repl, red = sympy.cse(list(exprs))
@@ -329,7 +383,10 @@ class SympyPDE:
         flux_cases, eig_cases = [], []
         for d in range(self.max_dim):
             flux_cases.append("        case %d: {\n%s\n        } break;" % (d, self._block(self.flux_exprs[d], ["F[%d]" % v for v in range(n)], "            ")))
-            eig_cases.append("        case %d: {\n%s\n            return lam;\n        }" % (d, self._block([self.eig_exprs[d]], ["const double lam"], "            ")))
+        # the eigenvalue members take a run-time, per-LANE normal in the Riemann kernels: ONE straight-line block for all directions (what they share is
+        # computed once), the lane's direction picked by selects -- see _source_tuned (a `switch (d)` ran every direction's divisions and square root in turn)
+        md = self.max_dim
+        eig_cases = [self._eig_block([self.eig_exprs[d] for d in range(md)], "        ")]
         src_member = ""
         if self.source_exprs is not None:
             src_member = ("    static constexpr bool HAS_SOURCE = true;\n"
@@ -404,9 +461,12 @@ class SympyPDE:
         n, na, md = self.n_vars, m["na"], self.max_dim
         ind = "            "
         aux_ieee, aux_fast, flux_d, flux_sc, dir_member = m["aux_ieee"], m["aux_fast"], m["flux_d"], m["flux_sc"], m["dir_member"]
-        eig_fast = []
-        for d in range(md):
-            eig_fast.append("        case %d: {\n%s\n            return lam;\n        }" % (d, self._block([self.eig_exprs[d]], ["const double lam"], ind, fast=True)))
+        # maxeig_fast: stage B calls it with a per-LANE normal (tasks (cell, face, node) packed densely over a wave), so a `switch (d)` runs every
+        # direction's block in turn under masks -- with its own reciprocal and square root each (r4: 17.5 against 15.5 ms per 128^3 launch of stage B, an
+        # HBM-bound kernel).  Straight-line code instead: the directions' expressions in ONE block (what they share -- 1/rho, the pressure, the sound
+        # speed -- is computed once by the common-subexpression pass), the lane's direction picked by selects; where d is a compile-time constant after
+        # inlining, the unused directions fold away.
+        eig_fast = self._eig_block([self.eig_exprs[d] for d in range(md)], "        ", fast=True)
         return """// generated by exahype_amd/pde_codegen.py from SymPy expressions -- user PDE term set "%s"
 #pragma once
 #include <hip/hip_runtime.h>
@@ -443,21 +503,15 @@ struct UserPDE {
         }
     }
 %s    __device__ static inline double maxeig(const double* q, int d) {
-        switch (d) {
 %s
-        }
-        return 0.0;
     }
     __device__ static inline double maxeig_fast(const double* q, int d) {
-        switch (d) {
 %s
-        }
-        return 0.0;
     }
 %s};
 }  // namespace exa
 """ % (self.name, n, n, na, md, aux_ieee, aux_fast, "\n".join(flux_cases), "\n".join(flux_d), "\n".join(flux_sc), dir_member,
-       "\n".join(eig_cases), "\n".join(eig_fast), src_member)
+       "\n".join(eig_cases), eig_fast, src_member)
 
     def _source_xt(self, flux_cases, eig_cases, src_member):
         """Term set whose expressions contain the volume centre x or the time t: the *_xt members carry them (fv_rusanov.hip uses them
@@ -521,10 +575,7 @@ struct UserPDE {
         }
     }
     __device__ static inline double maxeig_xt(const double* q, const double* x, double t, int d) {
-        switch (d) {
 %s
-        }
-        return 0.0;
     }
     __device__ static inline void flux_rt(const double* q, int d, double* F) { const double x0[3] = {0.0, 0.0, 0.0}; flux_xt(q, x0, 0.0, d, F); }
 %s    __device__ static inline double maxeig(const double* q, int d) { const double x0[3] = {0.0, 0.0, 0.0}; return maxeig_xt(q, x0, 0.0, d); }

@@ -1,5 +1,5 @@
 """Stage B (Riemann solve + corrector) alone on a 3-D block: ms per launch and the algorithmic HBM rate (development aid).
-usage: quick_bench_stage_b.py N cells [reps]"""
+usage: quick_bench_stage_b.py N cells [reps]      (EXA_SB_SYMPY=1: the same system as SymPy expressions, bench.sympy_euler())"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,11 @@ from exahype_amd import solvers as exa
 
 N, nc = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-s = exa.AderDgSolver(3, N, (nc,) * 3, pde=exa.PDE_EULER, n_vars=5)
+pde = exa.PDE_EULER
+if os.environ.get("EXA_SB_SYMPY"):
+    from bench import sympy_euler
+    pde = sympy_euler().register()
+s = exa.AderDgSolver(3, N, (nc,) * 3, pde=pde, n_vars=5)
 g = torch.Generator(device='cuda'); g.manual_seed(4)
 sh = s.u.shape[:-1]
 rho = 1 + 0.2 * torch.rand(sh, generator=g, device='cuda', dtype=torch.float64)

@@ -1,7 +1,10 @@
 set -e
-mkdir -p gpurun_out
-L=gpurun_out/r5h_m8.log
-: > $L
-for t in xi pl pl_noilp pl_s0 xi; do echo "== $t" >> $L; timeout -k 10 120 scripts/bin/bench_reg_n8_$t 64 2 2>&1 | grep -E "reg|max" >> $L; done
-echo "== stamps pl" >> $L; timeout -k 10 120 scripts/bin/bench_reg_n8_pl_stamps 32 2 >> $L 2>&1
+L=gpurun_out/r5n_stage_b.log; : > $L
+for r in 1 2; do
+python scripts/quick_bench_stage_b.py 6 128 10 2>&1 | tail -1 >> $L
+EXA_SB_SYMPY=1 python scripts/quick_bench_stage_b.py 6 128 10 2>&1 | tail -1 | sed 's/^/sympy: /' >> $L
+done
+EXA_SB_SYMPY=1 python scripts/quick_bench_stage_b.py 8 64 10 2>&1 | tail -1 | sed 's/^/sympy: /' >> $L
+python scripts/quick_bench_stage_b.py 8 64 10 2>&1 | tail -1 >> $L
 cat $L
+python -m pytest tests/test_user_pde.py -m gpu -x -q 2>&1 | tail -2
