@@ -675,6 +675,9 @@ def run_fv_grid(a, torch, exa, local):
                             "volume_updates_per_s": vols / t_full, "algorithmic_gbs": b_alg / t_step / 1e9,
                             "frac_of_hbm_peak": b_alg / t_step / 1e9 / HBM_PEAK_GBS, "bare_kernel_algorithmic_gbs": b_bare / t_bare / 1e9,
                             "finite": bool(torch.isfinite(fv.interior_device()).all().item())}
+        tr, src = read_traffic({"ref-4x4": "traffic_fv_grid_4x4.json", "limiter-15^3": "traffic_fv_grid_15.json"}[name])
+        out_shapes[name].update({"traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": b_alg,
+                                 "traffic_over_algorithmic": (tr / b_alg) if tr else None})
         del fv, U
         torch.cuda.empty_cache()
     r = out_shapes["ref-4x4"]
@@ -686,7 +689,8 @@ def run_fv_grid(a, torch, exa, local):
             "finite": all(v["finite"] for v in out_shapes.values()),
             "roofline": {"kernel": "fv_rusanov_kernel<..., GRID> (4x4) / fv_rusanov_slab_kernel<..., GRID> (15^3)", "bound": "hbm",
                          "bound_basis": "algorithmic bytes of the halo-less arrays (every state read once, written once: 16 V B per volume)", "achieved": r["algorithmic_gbs"],
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac_of_hbm_peak"], "traffic": None},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac_of_hbm_peak"], "traffic": r["traffic"], "traffic_source": r["traffic_source"],
+                         "traffic_15cubed": out_shapes["limiter-15^3"]["traffic"], "traffic_over_algorithmic_15cubed": out_shapes["limiter-15^3"]["traffic_over_algorithmic"]},
             "shapes": out_shapes}
 
 

@@ -52,6 +52,11 @@ struct FvCellData {
                               // CFL scan of the next step without a pass of its own (integer atomic max: zeroed by the launcher)
     int grid_on;
 };
+// logical block of workgroup b when each of the 8 XCDs (which take the workgroups of a launch round-robin) is to work on a contiguous range
+__device__ inline long fv_xcd_contiguous(long b, long n) {
+    const long per = n / 8;
+    return b < per * 8 ? (b % 8) * per + b / 8 : b;
+}
 // wave-level maximum -> one atomic per wave (non-negative doubles order like their bit patterns)
 __device__ inline void fv_lam_commit(double* lam, double mx) {
 #pragma unroll
@@ -760,7 +765,11 @@ __global__ void __launch_bounds__(SLAB_NT, 2)
 fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, double dt, double dt_over_h,
                        const long* __restrict__ slot, FvCellData cd) {
     extern __shared__ __attribute__((aligned(16))) double ring[];
-    if (slot && slot[blockIdx.x] < 0) return;                      // patch not in use (workgroup-uniform)
+    // grid step: workgroup b of a launch runs on XCD b % 8 -- each XCD takes a CONTIGUOUS range of patches, so that the boundary layers a patch reads
+    // from its y / z neighbours (40-byte pieces of 128-byte lines along z) are lines the same L2 holds for the neighbour's own sweep, in flight at the
+    // same time (r4: 1.32 x the algorithmic bytes left the L2s at 15^3 patches with the round-robin order)
+    const long patch = GRID ? fv_xcd_contiguous(blockIdx.x, gridDim.x) : (long)blockIdx.x;
+    if (slot && slot[patch] < 0) return;                           // patch not in use (workgroup-uniform)
     constexpr int NA = CACHE ? 3 : 1;
     constexpr int NQ = (CACHE || FITNV) ? PDE::NV : MAXV;                    // state entries kept per volume (cached variant: m == NV)
     const int S = P + 2 * H;
@@ -770,8 +779,8 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
     double* auxr = ring + 3 * slotd;                              // [2][S*S][nz(NA)]   (CACHE only)
     const int orow = S * V;
     const int dplane = P * P * V;                                 // grid step: doubles of a halo-less plane
-    double* Qp = Q + (long)blockIdx.x * (GRID ? (long)P * dplane : (long)S * plane);
-    [[maybe_unused]] double* Qo = GRID ? cd.out + (long)blockIdx.x * P * dplane : Qp;
+    double* Qp = Q + patch * (GRID ? (long)P * dplane : (long)S * plane);
+    [[maybe_unused]] double* Qo = GRID ? cd.out + patch * P * dplane : Qp;
     const int tid = threadIdx.x;
     // rows of the plane at a pitch of 16 lanes (P <= 16): a 32-lane group holds two whole rows, whose volume indices are distinct
     // mod 32 -- with V odd every per-volume LDS read of the group is conflict-free (rows packed at a pitch of P wrap around: 2 lanes
@@ -788,7 +797,7 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
     [[maybe_unused]] const double* nb_hi = Qp;
     [[maybe_unused]] bool bnd_lo = false, bnd_hi = false;
     if constexpr (GRID) {
-        const long b = blockIdx.x;
+        const long b = patch;
         const int g0 = (int)(b / ((long)cd.g[1] * cd.g[2]));
         const long rest = b - (long)g0 * cd.g[1] * cd.g[2];
         bnd_lo = cd.bstate && g0 == 0;
@@ -877,7 +886,7 @@ fv_rusanov_slab_kernel(double* __restrict__ Q, int P, int H, int m, int V, doubl
     if constexpr (GRID) {
         const int nhe = 4 * H * P * V;
         int pgc[3];
-        fv_grid_coords<3>(cd, (long)blockIdx.x, pgc);
+        fv_grid_coords<3>(cd, patch, pgc);
 #pragma unroll
         for (int r = 0; r < SLAB_NH; r++) {
             const int e0 = tid + r * SLAB_NT, e = e0 < nhe ? e0 : nhe - 1;
