@@ -34,6 +34,7 @@ PY
 echo "== bench lines"; 
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; tail -c 600 $OUT/bench_cfg2.json; echo
 python3 bench.py --gpus 1 --self-exchange --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg2_self_exchange.json 2> $OUT/bench_cfg2_self_exchange.err; tail -c 400 $OUT/bench_cfg2_self_exchange.json; echo
+python3 bench.py --config cfg4 --gpus 1 --self-exchange --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg4_self_exchange.json 2> $OUT/bench_cfg4_self_exchange.err; tail -c 400 $OUT/bench_cfg4_self_exchange.json; echo
 for cfg in cfg1 cfg4 fv-ref fv-grid cfg2_sympy cfg4_sympy; do python3 bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; tail -c 300 $OUT/bench_$cfg.json; echo; done
 echo "== kernel trace of the headline command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/trace_cfg2.log 2>&1
@@ -64,6 +65,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 xs.append(float(r["Counter_Value"]))
     print("fv_rusanov_slab_kernel in cfg4:", c, "n=%d mean=%.6g KiB" % (len(xs), sum(xs) / max(len(xs), 1)))
 PY
+echo "== matrix-instruction counters of the p = 7 stage A (32^3 cells)"
+scripts/pmc_m8.sh $OUT > $OUT/pmc_m8.txt 2>&1 || tail -5 $OUT/pmc_m8.txt
+tail -1 $OUT/pmc_m8.txt
 echo "== SQ counters of stage A (48^3 cells)"
 scripts/pmc_stage_a.sh ${TAG}sq 48 5 > $OUT/pmc_stage_a_48cubed.txt 2>&1 || tail -5 $OUT/pmc_stage_a_48cubed.txt
 python3 scripts/stage_a_pmc_json.py "$OUT/pmc_stage_a_48cubed.txt" "$OUT/stage_a_pmc.json" 48 5
