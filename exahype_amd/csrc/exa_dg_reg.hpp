@@ -99,14 +99,21 @@ template <int N, class PDE, int CPW = 1> struct StageAReg {
     static constexpr int SOFF = NVA * VS;                             // S_d at SOFF + d * QSZ
     // ncp term sets: three more arrays G_d = (D q) / h_d behind the sums -- the derive phase contracts q itself along its pencils, the node OWNER
     // evaluates B_d(q) G_d with the state it holds in registers (one cell per workgroup: 128 KB)
+    // r5 (EXA_REG_NCP_ALIAS, default): the gradients take the place of the SUMS instead -- a step becomes [gradients] barrier [owners: B_d(q) G_d into
+    // registers] barrier [flux sums] barrier [fold]; two more barriers per step, but the cell image is the 76 KB of a term set without ncp again, and two
+    // cells are in flight per CU as everywhere else (one cell per CU = one wave per SIMD was the 2 x of profiles/r04_xt_ncp_kernels.txt)
+#ifndef EXA_REG_NCP_ALIAS
+#define EXA_REG_NCP_ALIAS 1
+#endif
     static constexpr bool NCPV = pde_has_ncp<PDE>::value;
-    static constexpr int GOFF = SOFF + 3 * QSZ;
-    static constexpr int PIC_D = SOFF + (NCPV ? 6 : 3) * QSZ;
+    static constexpr bool GALIAS = NCPV && EXA_REG_NCP_ALIAS != 0;
+    static constexpr int GOFF = GALIAS ? SOFF : SOFF + 3 * QSZ;
+    static constexpr int PIC_D = SOFF + ((NCPV && !GALIAS) ? 6 : 3) * QSZ;
     static constexpr int FS = G::NN;                                  // closing phases: [array][var][node], arrays qbar | Fbar_x | Fbar_y | Fbar_z (| source)
     static constexpr int FIN_D = (pde_has_source<PDE>::value ? 5 : 4) * NV * FS;
     static constexpr int CELL_D = PIC_D > FIN_D ? PIC_D : FIN_D;      // doubles of LDS per cell in flight
     static constexpr size_t LDS_BYTES = sizeof(double) * ((size_t)CELL_D * CPW + 2 * 3 * N);   // + the one-kernel step's corrector weights
-    static constexpr bool FITS = G::NN <= NT && (NCPV ? 1 : 2) * sizeof(double) * (size_t)CELL_D + 2048 <= 160 * 1024;
+    static constexpr bool FITS = G::NN <= NT && ((NCPV && !GALIAS) ? 1 : 2) * sizeof(double) * (size_t)CELL_D + 2048 <= 160 * 1024;
     // behind the image of dg_stage_a_kernel (StageA<3, N, PDE, CPB>::IMAGE_BYTES): lane -> packed derive task of a two-level
     // step, and of iteration 0 (one level); packed = d | level slot << 2 | pencil << 3, -1 = idle
     static constexpr int TAB_INTS = 2 * NT;
@@ -136,9 +143,9 @@ __device__ inline void lds_barrier() {
 // gradient arrays G_d = (D q) / h_d sit in LDS behind the sums (StageAReg::GOFF; 128 KB per cell), the node owners evaluate B_d(q) G_d.
 // (First form: B_d(q_i) (D q)_i evaluated along the pencil in the derive phase -- six states at once on top of the owner state, ~290 VGPRs,
 // 25 - 30 ms per 32^3 launch of Euler-with-pressure-as-ncp against 26.3 of the plain kernel; this form: 12.2 ms, profiles/r04_xt_ncp_kernels.txt.)
-template <class PDE> constexpr int REG_CPW_OF = pde_has_ncp<PDE>::value ? 1 : EXA_REG_CPW_DEFAULT;
+template <class PDE> constexpr int REG_CPW_OF = (pde_has_ncp<PDE>::value && !EXA_REG_NCP_ALIAS) ? 1 : EXA_REG_CPW_DEFAULT;
 template <int N, class PDE, int CPW, bool FUSE = false>
-__global__ void __launch_bounds__(256 * CPW, (pde_has_ncp<PDE>::value ? 1 : 2))
+__global__ void __launch_bounds__(256 * CPW, ((pde_has_ncp<PDE>::value && !EXA_REG_NCP_ALIAS) ? 1 : 2))
 dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ trace,
                       long ncells, CellBox box, double dt, double idx0, double idx1, double idx2, int n_it,
                       const void* __restrict__ ops_raw, const int* __restrict__ tab, const void* __restrict__ step_raw, RegFuse fz, PlainGeo geo) {
@@ -411,17 +418,21 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
     // (-DEXA_REG_SPLIT, CPW == 2: a barrier between the halves, i.e. three segments of similar length per step, the second cell in flight one
     //  segment behind the first -- measured 9 % SLOWER than two segments: a barrier costs more than the better balance returns,
     //  profiles/r03_reg_kernel.txt)
-    using M0 = std::integral_constant<int, 0>;                       // derive: the derivative sums
-    using M1 = std::integral_constant<int, 1>;                       // ... only their non-conservative part
+    using M0 = std::integral_constant<int, 0>;                       // derive: the derivative sums (with their gradients G_d where those have arrays of their own)
+    using M1 = std::integral_constant<int, 1>;                       // ... only the gradients
+    using M2 = std::integral_constant<int, 2>;                       // ... only the flux sums (GALIAS: the gradients were a phase of their own)
+    constexpr bool GALIAS = SA::GALIAS;
     constexpr bool SPLIT_DIR = FXT || !pde_has_dir<PDE>::value;
     auto derive = [&](const Task& tk, const DirFlux<PDE>& fx, const double (&Em)[NE], double tA, double tB, auto mode) {
         // the derive stream is the long one of a step: it gets the SIMD's issue slots ahead of the co-resident wave of the other cell in
         // flight (in its fold / load / closing segment) -- 8 % of the launch (profiles/r03_reg_kernel.txt)
         __builtin_amdgcn_s_setprio(EXA_REG_PRIO);
         double e[H][NV], o[H][NV];
-        derive_g(tk, Em);
+        constexpr int MODE = decltype(mode)::value;
+        static_assert(!(GALIAS && MODE == 0), "gradients and sums share their arrays: two phases (M1, owners, M2)");
+        if constexpr (MODE != 2) derive_g(tk, Em);
         auto front = [&](auto dc) {                                    // the direction-dependent part: term calls
-            if constexpr (decltype(mode)::value == 0) derive_a(dc, tk, fx, e, o, tA, tB);
+            if constexpr (MODE != 1) derive_a(dc, tk, fx, e, o, tA, tB);
         };
         if constexpr (SPLIT_DIR) {
             // no per-lane-normal form of the flux (DirFlux<PDE, true>): the lanes of a wave take the branch of their direction, the term
@@ -432,7 +443,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         } else {
             front(std::integral_constant<int, -1>{});
         }
-        if constexpr (decltype(mode)::value == 0) {
+        if constexpr (MODE != 1) {
 #ifdef EXA_REG_SPLIT
             if constexpr (CPW == 2) bar();
 #endif
@@ -639,11 +650,20 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
             EXA_STAMP(0);
             bar();
             EXA_STAMP(1);
+            [[maybe_unused]] double nd0[NV];                               // GALIAS: the owner's ncp term of iteration 0
             {
                 Task tk1;
                 DirFlux<PDE> fx1(0, 0.0);
                 decode(opaque_v(pk1), tk1, fx1);
-                derive(tk1, fx1, Em, 0.0, 0.0, M0{});
+                if constexpr (GALIAS) {                                    // gradients | owners | flux sums
+                    derive(tk1, fx1, Em, 0.0, 0.0, M1{});
+                    bar();
+                    if (owner) ncp_at_owner(un, 0, 0, nd0);
+                    bar();
+                    derive(tk1, fx1, Em, 0.0, 0.0, M2{});
+                } else {
+                    derive(tk1, fx1, Em, 0.0, 0.0, M0{});
+                }
             }
             EXA_STAMP(2);
             bar();
@@ -667,7 +687,12 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 }
                 if constexpr (NCP) {                                       // + sum_d B_d(q) (D q) / h_d
                     double nd[NV];
-                    ncp_at_owner(un, 0, 0, nd);
+                    if constexpr (GALIAS) {
+    #pragma unroll
+                        for (int v = 0; v < NV; v++) nd[v] = nd0[v];
+                    } else {
+                        ncp_at_owner(un, 0, 0, nd);
+                    }
     #pragma unroll
                     for (int v = 0; v < NV; v++) S[v] += nd[v];
                 }
@@ -695,8 +720,20 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
         };
         constexpr int IT0 = XT ? 0 : 1;                                // first full iteration
         if (n_it > IT0 && owner) load_levels(std::integral_constant<int, 0>{}, q);
+        // r5 (EXA_REG_DEFER_FOLD: 0 never, 1 term sets with an ncp or with terms that see x, t (default), 2 every term set): the time contraction of an iteration DEFERRED to its end, as in
+        // exa_dg_m8.hpp -- a fold only keeps S_x + S_y + S_z (+ source / ncp terms) of its two levels; the owner state in front of the derive phases is
+        // the levels not yet in LDS + the sums so far (30 doubles) instead of iterate + accumulators (60).  That is what lets the ncp variant, whose owners
+        // hold their products over the flux phase, run two cells per CU under the 256-VGPR cap (108 spilled registers with the immediate fold).
+#ifndef EXA_REG_DEFER_FOLD
+#define EXA_REG_DEFER_FOLD 1
+#endif
+        // Measured (r5, profiles/r05_xt_ncp_kernels.txt): ncp 11.8 -> 10.1 ms per 32^3 launch (with the two cells per CU it allows), x,t source 6.09 -> 5.91;
+        // the built-in Euler set LOSES 15 % (175.6 against 152.3 ms per 128^3 launch: no spills to win back, and the contraction of a whole iteration in ONE
+        // fold unbalances the two cells in flight, whose folds run beside each other's derive phases) -- hence not for term sets of the state alone.
+        constexpr bool DEFER_FOLD = EXA_REG_DEFER_FOLD == 2 || (EXA_REG_DEFER_FOLD == 1 && (NCP || XT));
         for (int it = IT0; it < n_it; it++) {
             double acc[N][NV];
+            [[maybe_unused]] double Sk[DEFER_FOLD ? N : 1][NV];
             static_for<0, LS>([&](auto sc_) {
                 constexpr int st = decltype(sc_)::value;
                 constexpr int l0 = st * 2;
@@ -706,21 +743,35 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                 bar();
                 EXA_STAMP(6);
                 static_assert(NL == 2, "odd N: the last step of an iteration has one level -- mask the tasks of level slot 1");
-                derive(tk2, fx2, Em, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M0{});
+                [[maybe_unused]] double ndk[NL][NV];                   // GALIAS: the owner's ncp terms of the step's levels
+                if constexpr (GALIAS) {                                // gradients | owners: B_d(q) G_d | flux sums (into the arrays the gradients held)
+                    derive(tk2, fx2, Em, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M1{});
+                    bar();
+                    if (owner) {
+#pragma unroll
+                        for (int ls = 0; ls < NL; ls++) ncp_at_owner(q[l0 + ls], ls, l0 + ls, ndk[ls]);
+                    }
+                    bar();
+                    derive(tk2, fx2, Em, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M2{});
+                } else {
+                    derive(tk2, fx2, Em, XT ? level_t(l0) : 0.0, XT ? level_t(l0 + 1) : 0.0, M0{});
+                }
                 // what the fold needs from memory, requested in front of the barrier: -dt T[l'][l0 + ls] (l' fastest) and, where the
                 // iteration starts its accumulators, u
-                double Tm[NL * N], uu[NV];
+                [[maybe_unused]] double Tm[NL * N], uu[NV];
+                if constexpr (!DEFER_FOLD) {
 #pragma unroll
-                for (int k = 0; k < NL * N; k++) Tm[k] = step_here<N>(step_raw)->TdtT[l0 * N + k];
-                if constexpr (st == 0) {
+                    for (int k = 0; k < NL * N; k++) Tm[k] = step_here<N>(step_raw)->TdtT[l0 * N + k];
+                    if constexpr (st == 0) {
 #pragma unroll
-                    for (int v = 0; v < NV; v++) uu[v] = ukeep[v];
+                        for (int v = 0; v < NV; v++) uu[v] = ukeep[v];
+                    }
                 }
                 EXA_STAMP(7);
                 bar();
                 EXA_STAMP(8);
                 if (owner) {
-                    spin(Tm);
+                    if constexpr (!DEFER_FOLD) spin(Tm);
                     double Sx[NL][NV], Sy[NL][NV], Sz[NL][NV];         // every load first
 #pragma unroll
                     for (int ls = 0; ls < NL; ls++) {
@@ -748,11 +799,37 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
 #pragma unroll
                         for (int ls = 0; ls < NL; ls++) {
                             double nd[NV];
-                            ncp_at_owner(q[l0 + ls], ls, l0 + ls, nd);
+                            if constexpr (GALIAS) {
+#pragma unroll
+                                for (int v = 0; v < NV; v++) nd[v] = ndk[ls][v];
+                            } else {
+                                ncp_at_owner(q[l0 + ls], ls, l0 + ls, nd);
+                            }
 #pragma unroll
                             for (int v = 0; v < NV; v++) Sx[ls][v] += nd[v];
                         }
                     }
+                    if constexpr (DEFER_FOLD) {
+#pragma unroll
+                        for (int ls = 0; ls < NL; ls++)
+#pragma unroll
+                            for (int v = 0; v < NV; v++) Sk[l0 + ls][v] = Sx[ls][v];
+                        if constexpr (st + 1 == LS) {                  // every level's sums are there: q := u - dt T S, two input levels per batch of scalar operands
+                            static_for<0, LS>([&](auto s2_) {
+                                constexpr int s2 = decltype(s2_)::value;
+                                constexpr int m0 = s2 * 2;
+                                double T2[NL * N];
+                                sload<NL * N>(step_here<N>(step_raw)->TdtT + m0 * N, T2);
+#pragma unroll
+                                for (int ls = 0; ls < NL; ls++)
+#pragma unroll
+                                    for (int lp = 0; lp < N; lp++)
+#pragma unroll
+                                        for (int v = 0; v < NV; v++)
+                                            acc[lp][v] = fma(T2[ls * N + lp], Sk[m0 + ls][v], (s2 == 0 && ls == 0) ? ukeep[v] : acc[lp][v]);
+                            });
+                        }
+                    } else {
 #pragma unroll
                     for (int ls = 0; ls < NL; ls++)
 #pragma unroll
@@ -762,6 +839,7 @@ dg_stage_a_reg_kernel(const double* u_in, double* u_out, double* __restrict__ tr
                                 if constexpr (st == 0) acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], ls == 0 ? uu[v] : acc[lp][v]);
                                 else acc[lp][v] = fma(Tm[ls * N + lp], Sx[ls][v], acc[lp][v]);
                             }
+                    }
                     // the last step of an iteration completes the new iterate: its first levels go to LDS right away
                     if constexpr (st + 1 == LS) {
                         if (it + 1 < n_it) load_levels(std::integral_constant<int, 0>{}, acc);

@@ -591,6 +591,7 @@ struct UserPDE {
             h.update(open(os.path.join(CSRC, f), "rb").read())
         h.update(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "build.py"), "rb").read())      # (compiler flags)
         h.update(repr(self.dg_flags).encode())
+        h.update(os.environ.get("EXA_EXTRA_FLAGS", "").encode())       # (development builds with extra -D macros: a library of their own)
         return h.hexdigest()[:16]
 
     # -- build + registration ----------------------------------------------------------------------
@@ -613,7 +614,7 @@ struct UserPDE {
             f.write(self.source())
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         common = [hipcc, "-O3", "-fPIC", "-std=c++17", "--offload-arch=%s" % _build.ARCH, "-Wno-unused-function",
-                  "-Wno-pass-failed", "-I", CSRC, "-DEXA_PDE_ID=100", '-DEXA_USER_PDE_HEADER="%s"' % hdr]
+                  "-Wno-pass-failed", "-I", CSRC, "-DEXA_PDE_ID=100", '-DEXA_USER_PDE_HEADER="%s"' % hdr] + os.environ.get("EXA_EXTRA_FLAGS", "").split()
         sched = self.dg_flags if self.dg_flags is not None else _build.DG_SCHED
         units = [("fv_rusanov.hip", "fv.o", ["-ffp-contract=off"]), ("dg_inst.hip", "dg2.o", ["-DEXA_DIM=2", "-DEXA_UNIT_A"] + sched),
                  ("dg_inst.hip", "dg2b.o", ["-DEXA_DIM=2", "-DEXA_UNIT_B"])]

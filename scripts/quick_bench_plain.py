@@ -1,6 +1,6 @@
 """Stage A for term sets with position- / time-dependent terms or a non-conservative product (development aid): ms per launch on 3-D cells,
 Euler with a source that depends on x and t (`xt`) and, optionally, the pressure gradient moved into a non-conservative product (`ncp`).
-usage: quick_bench_plain.py N cells [xt|ncp]"""
+usage: quick_bench_plain.py N cells [xt|ncp] [build]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, sympy
@@ -43,6 +43,9 @@ def ncp(q, dq, d):
 
 
 p = SympyPDE(5, flux, eig, max_dim=3, name="euler_" + kind, source=source, ncp=ncp if kind == "ncp" else None)
+if len(sys.argv) > 4 and sys.argv[4] == "build":                  # (no GPU needed: compile the term set's library in-tree so that it travels, print its path)
+    print(p.build())
+    sys.exit(0)
 s = exa.AderDgSolver(3, N, (n, n, n), pde=p.register(), n_vars=5, origin=[0.1, 0.2, 0.3], time=0.5)
 g = torch.Generator(device='cuda'); g.manual_seed(4)
 sh = s.u.shape[:-1]

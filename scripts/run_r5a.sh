@@ -1,10 +1,12 @@
 set -e
-L=gpurun_out/r5n_stage_b.log; : > $L
+L=gpurun_out/r5r_defer.log; : > $L
+V=exahype_amd/lib/var_defer2/libexahype_hip.so
 for r in 1 2; do
-python scripts/quick_bench_stage_b.py 6 128 10 2>&1 | tail -1 >> $L
-EXA_SB_SYMPY=1 python scripts/quick_bench_stage_b.py 6 128 10 2>&1 | tail -1 | sed 's/^/sympy: /' >> $L
+python scripts/quick_bench_stage_a.py 6 128 3 2>&1 | tail -1 | sed 's/^/euler default: /' >> $L
+EXA_LIB=$V python scripts/quick_bench_stage_a.py 6 128 3 2>&1 | tail -1 | sed 's/^/euler defer2: /' >> $L
 done
-EXA_SB_SYMPY=1 python scripts/quick_bench_stage_b.py 8 64 10 2>&1 | tail -1 | sed 's/^/sympy: /' >> $L
-python scripts/quick_bench_stage_b.py 8 64 10 2>&1 | tail -1 >> $L
+python scripts/quick_bench_sympy.py 6 64 3 2>&1 | tail -3 | sed 's/^/sympy default: /' >> $L
+EXA_EXTRA_FLAGS="-DEXA_REG_DEFER_FOLD=2" python scripts/quick_bench_sympy.py 6 64 3 2>&1 | tail -3 | sed 's/^/sympy defer2: /' >> $L
+python scripts/quick_bench_plain.py 6 32 xt 2>&1 | tail -1 | sed 's/^/xt default: /' >> $L
+EXA_EXTRA_FLAGS="-DEXA_REG_DEFER_FOLD=2" python scripts/quick_bench_plain.py 6 32 xt 2>&1 | tail -1 | sed 's/^/xt defer2: /' >> $L
 cat $L
-python -m pytest tests/test_user_pde.py -m gpu -x -q 2>&1 | tail -2
