@@ -150,6 +150,45 @@ def test_dg_cfl_time_loop():
     assert rel_err(s.download().reshape(-1), ref) < 1e-10
 
 
+def test_cfl_step_rule():
+    """dt = min(scale / lambda_max, time left); lambda_max == 0.0 exactly: one step to the end; NaN / inf / negative: the run has diverged and says so
+    (r4 advice: fmax in the device reductions dropped a NaN and the loop went on with a finite lambda)."""
+    from exahype_amd.solvers import _cfl_step
+    assert _cfl_step(2.0, 1.0, 10.0, "t") == 0.5 and _cfl_step(2.0, 1.0, 0.25, "t") == 0.25 and _cfl_step(0.0, 1.0, 0.75, "t") == 0.75
+    for bad in (float("nan"), float("inf"), -1.0):
+        with pytest.raises(FloatingPointError, match="diverged"):
+            _cfl_step(bad, 1.0, 1.0, "t")
+
+
+@pytest.mark.gpu
+def test_run_continues_from_the_current_time_and_raises_on_a_diverged_state():
+    """Both solvers' run(t_end) integrate UNTIL `time` reaches t_end (r4: the DG loop integrated a duration from a local t = 0), and a NaN in the state
+    reaches the host as a NaN eigenvalue (device reductions keep it: exa_pde.hpp nan_max) and ends the run with an error instead of silently."""
+    import torch
+    from exahype_amd import solvers as exa
+    N, nc = 3, (3, 3)
+    u = euler_dg_state(nc + (N, N), seed=4)
+    s = exa.AderDgSolver(2, N, nc, n_vars=5, time=0.5)
+    s.upload(u)
+    lam = float(s.max_eigenvalue()[0])
+    dt = 0.3 * min(s.dx) / ((2 * N - 1) * 2 * lam)
+    assert s.run(0.5 + 1.5 * dt, cfl=0.3) == 2 and abs(s.time - (0.5 + 1.5 * dt)) < 1e-14
+    assert s.run(0.5 + 1.5 * dt, cfl=0.3) == 0                                  # already there
+    s.u[0, 0, 0, 0, 0] = float("nan")
+    with pytest.raises(FloatingPointError, match="diverged"):
+        s.run(s.time + dt, cfl=0.3)
+    for fused in (True, False):
+        fv = exa.FVPatchGrid(2, (3, 2), 4, 1, 5, 0, exa.PDE_EULER, exa.FV_RUSANOV, fused=fused)
+        fv.set_interior(_grid_state((3, 2), 4, 5, 3, 2))
+        t0 = fv.time
+        assert fv.run(t0 + 1e-3, cfl=0.3) >= 1 and abs(fv.time - (t0 + 1e-3)) < 1e-15
+        U = fv.interior()
+        U[1, 1, 2, 2, 0] = float("nan")
+        fv.set_interior(U)
+        with pytest.raises(FloatingPointError, match="diverged"):
+            fv.run(fv.time + 1e-3, cfl=0.3)
+
+
 def _grid_state(grid, P, V, seed, dim):
     """Euler-like admissible states [g.., P.., V]"""
     rng = np.random.default_rng(seed)
