@@ -222,34 +222,11 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 
     // one round: direction D, results to A (D = 1), B (D = 2) or into hx (D = 0)
     // tA / tB: times of the two level slots (XT); mode 0: the derivative sums, 1: only their non-conservative part (the closing pass)
-    // the operands of a round: states and cached scalars of the lane's two nodes (14 LDS loads), requested by round_load, used by round_rest -- so that a round's
-    // operands can be in flight under the round before it, or under the barrier in front of it (EXA_M8_PREFETCH)
-    struct RoundOps { double qa[NV], qb[NV], aa[nz(NA)], ab[nz(NA)]; int off; };
-    auto round_load = [&](auto dc, int tb, RoundOps& r) {
-        constexpr int D = decltype(dc)::value;
-        r.off = ltab[(tb * 3 + D) * NT + opaque_v(tid)];
-        if (r.off != 0xffff) {                                        // (wave-uniform: a wave has 16 pencils or none)
-            constexpr int ps = G::pstride(D);
-            const int dj0 = opaque_v(d_j);
-            const int dj = D == G::PERM_D ? G::ypair(dj0) : dj0;
-            const int na = r.off + dj * ps, nb = r.off + (N - 1 - dj) * ps;
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                r.qa[v] = EXA_SLD(na + v * VS);
-                r.qb[v] = EXA_SLD(nb + v * VS);
-            }
-#pragma unroll
-            for (int k = 0; k < NA; k++) {
-                r.aa[k] = EXA_SLD(AXO + na + k * VS);
-                r.ab[k] = EXA_SLD(AXO + nb + k * VS);
-            }
-        }
-    };
-    auto round_rest = [&](auto dc, const RoundOps& rops, double (&hx)[2][NV], [[maybe_unused]] double tA, [[maybe_unused]] double tB, auto mode) {
+    auto round = [&](auto dc, int tb, double (&hx)[2][NV], [[maybe_unused]] double tA, [[maybe_unused]] double tB, auto mode) {
         constexpr int D = decltype(dc)::value;
         constexpr int MODE = decltype(mode)::value;
-        const int off = rops.off;
-        if (off != 0xffff) {
+        const int off = ltab[(tb * 3 + D) * NT + opaque_v(tid)];
+        if (off != 0xffff) {                                          // (wave-uniform: a wave has 16 pencils or none)
             constexpr int ps = G::pstride(D);
             // (lane constants behind opaque copies: hoisted out of the cell loop their products with the strides live through the Picard
             // iterations and spill -- 96 B of scratch, reloaded in front of every round)
@@ -257,11 +234,17 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             const int dj = D == G::PERM_D ? G::ypair(dj0) : dj0;                 // the node pair (dj, 7 - dj) of this lane row
             const double oEe = D == G::PERM_D ? aEeY : aEe, oEo = D == G::PERM_D ? aEoY : aEo;
             const int na = off + dj * ps, nb = off + (N - 1 - dj) * ps;
-            const double (&qa)[NV] = rops.qa;
-            const double (&qb)[NV] = rops.qb;
-            const double (&aa)[nz(NA)] = rops.aa;
-            const double (&ab)[nz(NA)] = rops.ab;
-            double Fa[NV], Fb[NV];
+            double qa[NV], qb[NV], aa[nz(NA)], ab[nz(NA)], Fa[NV], Fb[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                qa[v] = EXA_SLD(na + v * VS);
+                qb[v] = EXA_SLD(nb + v * VS);
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                aa[k] = EXA_SLD(AXO + na + k * VS);
+                ab[k] = EXA_SLD(AXO + nb + k * VS);
+            }
             const double sc = D == 0 ? idx0 : (D == 1 ? idx1 : idx2);
             // XT: positions of the lane's two nodes, time of its level slot (pencil (a, b) and level slot decoded from the table's offset)
             [[maybe_unused]] double xa[3], xb[3], tl = 0.0;
@@ -349,14 +332,6 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             }
         }
     };
-    auto round = [&](auto dc, int tb, double (&hx)[2][NV], double tA, double tB, auto mode) {
-        RoundOps r;
-        round_load(dc, tb, r);
-        round_rest(dc, r, hx, tA, tB, mode);
-    };
-#ifndef EXA_M8_PREFETCH      // 1: r5, the operands of the second round requested in front of the first round's arithmetic, those of the in-place round in front of the barrier
-#define EXA_M8_PREFETCH 0
-#endif
 #ifndef EXA_M8_PIPE          // (measured SLOWER: 117.3 against 98.2 ms per 64^3 launch -- the 28 VGPRs of the next round's operands do not exist: 204 B of scratch)
 #define EXA_M8_PIPE 0
 #endif
@@ -461,22 +436,6 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 #endif
         // (EXA_M8_LAYOUT: the direction in place is y, the one whose stores are conflict-free in the layout of Q; before r5's layout it was x)
         constexpr int DL = EXA_M8_LAYOUT ? 1 : 0, DF = EXA_M8_LAYOUT ? 0 : 1;
-#if EXA_M8_PREFETCH
-        {
-            // the 14 loads of a round in flight under the arithmetic / the barrier in front of it (all three rounds read Q and the scalars, which only the
-            // in-place round writes -- behind the barrier)
-            RoundOps r1, r2;
-            round_load(std::integral_constant<int, DF>{}, tb, r1);
-            round_load(std::integral_constant<int, 2>{}, tb, r2);
-            round_rest(std::integral_constant<int, DF>{}, r1, hx, tA, tB, mode);
-            round_load(std::integral_constant<int, DL>{}, tb, r1);
-            round_rest(std::integral_constant<int, 2>{}, r2, hx, tA, tB, mode);
-            __syncthreads();                                          // every read of Q by the first two rounds is done (the third round's own reads are in its registers)
-            round_rest(std::integral_constant<int, DL>{}, r1, hx, tA, tB, mode);
-            __syncthreads();
-            return;
-        }
-#endif
         round(std::integral_constant<int, DF>{}, tb, hx, tA, tB, mode);
         EXA_RSTAMP(0);
         round(std::integral_constant<int, 2>{}, tb, hx, tA, tB, mode);

@@ -1,12 +1,4 @@
 set -e
-L=gpurun_out/r5r_defer.log; : > $L
-V=exahype_amd/lib/var_defer2/libexahype_hip.so
-for r in 1 2; do
-python scripts/quick_bench_stage_a.py 6 128 3 2>&1 | tail -1 | sed 's/^/euler default: /' >> $L
-EXA_LIB=$V python scripts/quick_bench_stage_a.py 6 128 3 2>&1 | tail -1 | sed 's/^/euler defer2: /' >> $L
-done
-python scripts/quick_bench_sympy.py 6 64 3 2>&1 | tail -3 | sed 's/^/sympy default: /' >> $L
-EXA_EXTRA_FLAGS="-DEXA_REG_DEFER_FOLD=2" python scripts/quick_bench_sympy.py 6 64 3 2>&1 | tail -3 | sed 's/^/sympy defer2: /' >> $L
-python scripts/quick_bench_plain.py 6 32 xt 2>&1 | tail -1 | sed 's/^/xt default: /' >> $L
-EXA_EXTRA_FLAGS="-DEXA_REG_DEFER_FOLD=2" python scripts/quick_bench_plain.py 6 32 xt 2>&1 | tail -1 | sed 's/^/xt defer2: /' >> $L
+L=gpurun_out/r5u_m8.log; : > $L
+for t in xi cur xi cur; do echo "== $t" >> $L; timeout -k 10 120 scripts/bin/bench_reg_n8_$t 64 2 2>&1 | grep -E "reg|max" >> $L; done
 cat $L
