@@ -8,9 +8,9 @@ is reproduced WITH its defects (`&&Q_copy`, `Flux(.
 execution path; the MI355X path is HIPPrinter.
 
 Own structure: statements are rendered by three small passes (loop plan -> index flattening ->
-name qualification) instead of the reference's recursive string surgery.  Not reproduced: the
-reference's `parse()` post-pass (`CPPPrinter.py:278-316`), which only acts when the first input is
-used as an object (`<input0>.member`); no known kernel triggers it.
+name qualification) instead of the reference's recursive string surgery; the reference's `parse()`
+post-pass (`CPPPrinter.py:278-316`: members of the first input, used as an object, indexed per patch)
+is one regular-expression substitution (`_members_per_patch`, r5).
 """
 from __future__ import annotations
 
@@ -55,7 +55,20 @@ class CPPPrinter(CodePrinter):
             else:
                 out.append(self.loop([lhs, rhs], direction, k.dim + 1, span))
         out += ['\n'] + ['\tdelete[] %s;\n' % name for name in temps] + ['}\n']
-        self.code = ''.join(out)
+        self.code = self._members_per_patch(''.join(out))
+
+    def _members_per_patch(self, text):
+        """The reference's `parse()` post-pass (`exahype/printers/CPPPrinter.py:278-316`, called at the end of its constructor), as one regular-expression
+        substitution: where the FIRST input is used as an object in the function body -- `<input0>.member` -- its members are arrays of per-patch entries:
+        `<input0>.member[<patch term> + rest]` becomes `<input0>.member[patch][rest]` (everything up to and including the first "+ " of the index is the
+        patch term the flattening put there) and a member without an index gets `[patch]`.  Member names are runs of letters, as in the reference.  Pinned by
+        tests/golden/cppprinter_member_input.txt (captured from the reference on a builder whose first input is a parent of its items)."""
+        k = self.kernel()
+        if not k.inputs:
+            return text
+        head, brace, body = text.partition('{')
+        pat = re.compile(re.escape(str(k.inputs[0])) + r'\.([A-Za-z]*)(\[[^+]*\+ )?')
+        return head + brace + pat.sub(lambda m: '%s.%s%s' % (k.inputs[0], m.group(1), '[patch][' if m.group(2) else '[patch]'), body)
 
     # -- pieces ---------------------------------------------------------------------------------------
     def _signature(self):

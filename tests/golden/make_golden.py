@@ -113,6 +113,14 @@ def main():
     with open(os.path.join(HERE, "cppprinter_3d_p15.txt"), "w") as f:
         f.write(sub.CPPPrinter(k3).code)
 
+    # the first input used as an OBJECT (a const with an in_type that is the parent of the items): the reference's parse() post-pass rewrites its members
+    km = pkg.KernelBuilder(dim=2, patch_size=4, halo_size=1, n_real=4, n_aux=0)
+    Data = km.const('patchData', in_type='::exahype2::CellData&')
+    Qo = km.item('QOut', parent=Data); Qi = km.item('QIn', parent=Data); dtm = km.const('dt', parent=Data)
+    km.single(Qi[0], Qo[0]); km.single(Qo[0], Qi[0] * dtm)
+    with open(os.path.join(HERE, "cppprinter_member_input.txt"), "w") as f:
+        f.write(sub.CPPPrinter(km).code)
+
     # error behaviour
     errs = {}
     for kw in (dict(dim=1, patch_size=4, halo_size=1), dict(dim=2, patch_size=0, halo_size=1), dict(dim=3, patch_size=4, halo_size=-1)):

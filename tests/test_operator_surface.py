@@ -183,6 +183,22 @@ def test_cpp_printer_text_equals_reference(golden_dir, name, make):
     assert p.functionName() == "time_step" and p.kernel().dim in (2, 3)
 
 
+def test_cpp_printer_members_of_the_first_input_are_indexed_per_patch(golden_dir):
+    """The reference's `parse()` post-pass (`exahype/printers/CPPPrinter.py:278-316`): where the first input is used as an object, `<input0>.member[<patch
+    term> + rest]` becomes `<input0>.member[patch][rest]` and an un-indexed member gets `[patch]` -- fixture captured from the reference on a builder whose
+    first input (a const with an in_type) is the parent of its items (tests/golden/make_golden.py); the other three fixtures never trigger the pass."""
+    from exahype_amd import KernelBuilder
+    from exahype_amd.printers import CPPPrinter
+    k = KernelBuilder(dim=2, patch_size=4, halo_size=1, n_real=4, n_aux=0)
+    data = k.const('patchData', in_type='::exahype2::CellData&')
+    qo, qi, dt = k.item('QOut', parent=data), k.item('QIn', parent=data), k.const('dt', parent=data)
+    k.single(qi[0], qo[0])
+    k.single(qo[0], qi[0] * dt)
+    code = CPPPrinter(k).code
+    assert code == open(os.path.join(golden_dir, "cppprinter_member_input.txt")).read()
+    assert "patchData.QIn[patch][16*(i - 1)" in code and "patchData.dt[patch]*" in code
+
+
 def test_cpp_printer_file_prepends_includes(tmp_path):
     from exahype_amd import KernelBuilder
     from exahype_amd.printers import CPPPrinter
