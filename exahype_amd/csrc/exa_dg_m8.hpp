@@ -486,6 +486,17 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         for (int k = 0; k < NA; k++) lds[AXO + o_off + ls * SL + k * VS] = a[k];
     };
 
+#ifndef EXA_M8_PREFETCH_U    // 1: the next cell's u requested behind the time averages of this one (in flight under the volume / trace / u* phases).
+#define EXA_M8_PREFETCH_U 0  // Measured r5: 89.5 against 88.4 ms per 64^3 launch -- the ten registers it holds cost 4 spilled VGPRs; off.
+#endif
+    [[maybe_unused]] double un[NV];
+    if constexpr (EXA_M8_PREFETCH_U) {
+        if ((long)blockIdx.x < box.nbox) {
+            const double* p0 = u_in + (box.cell(blockIdx.x) * NN + o_n) * NV;
+#pragma unroll
+            for (int v = 0; v < NV; v++) un[v] = p0[v];
+        }
+    }
     for (long b = blockIdx.x; b < box.nbox; b += gridDim.x) {
         const long cell = box.cell(b);
         if constexpr (XT) {
@@ -497,7 +508,7 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         const double* up = u_in + (cell * NN + o_n) * NV;             // (u is re-read where needed: an L2 hit against 10 VGPRs of a kernel at its cap)
         double u[NV], q[N][NV];
 #pragma unroll
-        for (int v = 0; v < NV; v++) u[v] = up[v];
+        for (int v = 0; v < NV; v++) u[v] = EXA_M8_PREFETCH_U ? un[v] : up[v];
 
         // (XT: the terms depend on the level time -- every iteration is a full one, started from q_l = u)
         if constexpr (XT) {
@@ -732,6 +743,13 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             }
         }
         EXA_STAMP(8);
+        if constexpr (EXA_M8_PREFETCH_U) {
+            if (b + gridDim.x < box.nbox) {
+                const double* pn = u_in + (box.cell(b + gridDim.x) * NN + opaque_v(o_n)) * NV;
+#pragma unroll
+                for (int v = 0; v < NV; v++) un[v] = pn[v];
+            }
+        }
         __syncthreads();
 
         // ---- volume integral (in place over Fbar_d) + face extrapolation: pencil tasks (d, v, t), t fastest

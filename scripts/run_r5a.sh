@@ -1,4 +1,4 @@
 set -e
-L=gpurun_out/r5w_n6_flags.log; : > $L
-for t in f0 f3 f1 f8 f0; do echo "== $t" >> $L; timeout -k 10 200 scripts/bin/bench_reg_n6_$t 64 2 2>&1 | grep -E "reg " >> $L; done
+L=gpurun_out/r5x_m8.log; : > $L
+for t in cur pu cur pu; do echo "== $t" >> $L; timeout -k 10 120 scripts/bin/bench_reg_n8_$t 64 2 2>&1 | grep -E "reg|max" >> $L; done
 cat $L
