@@ -222,10 +222,17 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
 
     // one round: direction D, results to A (D = 1), B (D = 2) or into hx (D = 0)
     // tA / tB: times of the two level slots (XT); mode 0: the derivative sums, 1: only their non-conservative part (the closing pass)
-    auto round = [&](auto dc, int tb, double (&hx)[2][NV], [[maybe_unused]] double tA, [[maybe_unused]] double tB, auto mode) {
+    // stage (EXA_M8_XEARLY): 0 the whole round; 1 only its 14 operand loads, handed out through `ext`; 2 everything behind them, the operands taken from `ext`
+    // -- the in-place round requests its operands in FRONT of the barrier it runs behind (they are in Q and the scalars, which nobody writes before it)
+    struct RoundOps { double qa[NV], qb[NV], aa[nz(NA)], ab[nz(NA)]; int off; };
+    auto round_staged = [&](auto dc, int tb, double (&hx)[2][NV], [[maybe_unused]] double tA, [[maybe_unused]] double tB, auto mode, auto stage, RoundOps& ext) {
         constexpr int D = decltype(dc)::value;
         constexpr int MODE = decltype(mode)::value;
-        const int off = ltab[(tb * 3 + D) * NT + opaque_v(tid)];
+        constexpr int ST = decltype(stage)::value;
+        int off;
+        if constexpr (ST == 2) off = ext.off;
+        else off = ltab[(tb * 3 + D) * NT + opaque_v(tid)];
+        if constexpr (ST == 1) ext.off = off;
         if (off != 0xffff) {                                          // (wave-uniform: a wave has 16 pencils or none)
             constexpr int ps = G::pstride(D);
             // (lane constants behind opaque copies: hoisted out of the cell loop their products with the strides live through the Picard
@@ -235,15 +242,30 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             const double oEe = D == G::PERM_D ? aEeY : aEe, oEo = D == G::PERM_D ? aEoY : aEo;
             const int na = off + dj * ps, nb = off + (N - 1 - dj) * ps;
             double qa[NV], qb[NV], aa[nz(NA)], ab[nz(NA)], Fa[NV], Fb[NV];
+            if constexpr (ST != 2) {
 #pragma unroll
-            for (int v = 0; v < NV; v++) {
-                qa[v] = EXA_SLD(na + v * VS);
-                qb[v] = EXA_SLD(nb + v * VS);
+                for (int v = 0; v < NV; v++) {
+                    qa[v] = EXA_SLD(na + v * VS);
+                    qb[v] = EXA_SLD(nb + v * VS);
+                }
+#pragma unroll
+                for (int k = 0; k < NA; k++) {
+                    aa[k] = EXA_SLD(AXO + na + k * VS);
+                    ab[k] = EXA_SLD(AXO + nb + k * VS);
+                }
             }
+            if constexpr (ST == 1) {
 #pragma unroll
-            for (int k = 0; k < NA; k++) {
-                aa[k] = EXA_SLD(AXO + na + k * VS);
-                ab[k] = EXA_SLD(AXO + nb + k * VS);
+                for (int v = 0; v < NV; v++) { ext.qa[v] = qa[v]; ext.qb[v] = qb[v]; }
+#pragma unroll
+                for (int k = 0; k < NA; k++) { ext.aa[k] = aa[k]; ext.ab[k] = ab[k]; }
+                return;
+            }
+            if constexpr (ST == 2) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) { qa[v] = ext.qa[v]; qb[v] = ext.qb[v]; }
+#pragma unroll
+                for (int k = 0; k < NA; k++) { aa[k] = ext.aa[k]; ab[k] = ext.ab[k]; }
             }
             const double sc = D == 0 ? idx0 : (D == 1 ? idx1 : idx2);
             // XT: positions of the lane's two nodes, time of its level slot (pencil (a, b) and level slot decoded from the table's offset)
@@ -332,6 +354,13 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
             }
         }
     };
+    auto round = [&](auto dc, int tb, double (&hx)[2][NV], double tA, double tB, auto mode) {
+        RoundOps none;
+        round_staged(dc, tb, hx, tA, tB, mode, std::integral_constant<int, 0>{}, none);
+    };
+#ifndef EXA_M8_XEARLY        // 1: the in-place round's operands requested in front of the barrier (r5).  Measured: 89.6 against 88.3 ms per 64^3 launch (no more
+#define EXA_M8_XEARLY 0      // registers, no spill -- the loads merely compete with the stores of the rounds in front of the barrier): off.
+#endif
 #ifndef EXA_M8_PIPE          // (measured SLOWER: 117.3 against 98.2 ms per 64^3 launch -- the 28 VGPRs of the next round's operands do not exist: 204 B of scratch)
 #define EXA_M8_PIPE 0
 #endif
@@ -440,9 +469,17 @@ dg_stage_a_m8_kernel(const double* __restrict__ u_in, double* __restrict__ u_out
         EXA_RSTAMP(0);
         round(std::integral_constant<int, 2>{}, tb, hx, tA, tB, mode);
         EXA_RSTAMP(1);
+#if EXA_M8_XEARLY
+        RoundOps xo;
+        round_staged(std::integral_constant<int, DL>{}, tb, hx, tA, tB, mode, std::integral_constant<int, 1>{}, xo);
+        __syncthreads();                                              // every read of Q by the first two rounds is done (this round's own are in its registers)
+        EXA_RSTAMP(2);
+        round_staged(std::integral_constant<int, DL>{}, tb, hx, tA, tB, mode, std::integral_constant<int, 2>{}, xo);
+#else
         __syncthreads();                                              // every read of Q by the first two rounds is done
         EXA_RSTAMP(2);
         round(std::integral_constant<int, DL>{}, tb, hx, tA, tB, mode);
+#endif
         EXA_RSTAMP(3);
         __syncthreads();                                              // the three directional sums are complete
         return;
