@@ -47,6 +47,7 @@ SIGNATURES = {
     "exa_dg_predictor_volume": (C.c_int, [_vp, _vp, _vp, C.c_double, _dp, _vp]),
     "exa_dg_predictor_volume_box": (C.c_int, [_vp, _vp, _vp, _lp, _lp, C.c_double, _dp, _vp]),
     "exa_dg_riemann_corrector": (C.c_int, [_vp, _vp, _vp, C.POINTER(_vp), _lp, _lp, C.c_double, _dp, _vp]),
+    "exa_dg_riemann_corrector_cfl": (C.c_int, [_vp, _vp, _vp, C.POINTER(_vp), _lp, _lp, C.c_double, _dp, _vp, _vp]),
     "exa_dg_plan_set_origin_time": (C.c_int, [_vp, _dp, C.c_double]),
     "exa_dg_has_corrector_predictor": (C.c_int, [_vp]),
     "exa_dg_corrector_predictor": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), _lp, _lp, C.c_double, C.c_double, _dp, _vp, _vp]),

@@ -476,10 +476,35 @@ int exa_dg_predictor_volume(exa_dg_plan* p, double* u_dev, double* trace_dev, do
     return exa_dg_predictor_volume_box(p, u_dev, trace_dev, nullptr, nullptr, dt, dx, stream);
 }
 
+static int riemann_corrector(exa_dg_plan* p, double* u_dev, const double* trace_dev, const double* const* ghost_dev,
+                             const long* lo, const long* hi, double dt, const double* dx, double* lambda_dev, void* stream);
+
 int exa_dg_riemann_corrector(exa_dg_plan* p, double* u_dev, const double* trace_dev, const double* const* ghost_dev,
                              const long* lo, const long* hi, double dt, const double* dx, void* stream) {
+    return riemann_corrector(p, u_dev, trace_dev, ghost_dev, lo, hi, dt, dx, nullptr, stream);
+}
+
+int exa_dg_riemann_corrector_cfl(exa_dg_plan* p, double* u_dev, const double* trace_dev, const double* const* ghost_dev,
+                                 const long* lo, const long* hi, double dt, const double* dx, double* lambda_dev, void* stream) {
+    if (!lambda_dev) { set_error("exa_dg_riemann_corrector_cfl: NULL lambda_dev"); return EXA_ERR_INVALID; }
+    if (p && (exa_pde_flags(p->pde) & EXA_PDE_FLAG_XT)) {
+        set_error("exa_dg_riemann_corrector_cfl: the eigenvalue of this term set depends on position / time -- its CFL scan needs the node coordinates (exa_pde_eval_device_at)");
+        return EXA_ERR_INVALID;
+    }
+    if (p) {
+        int rc = use_device(p->device);
+        if (rc) return rc;
+        hipError_t e = hipMemsetAsync(lambda_dev, 0, sizeof(double), (hipStream_t)stream);
+        if (e != hipSuccess) { set_error("exa_dg_riemann_corrector_cfl: memset: %s", hipGetErrorString(e)); return EXA_ERR_HIP; }
+    }
+    return riemann_corrector(p, u_dev, trace_dev, ghost_dev, lo, hi, dt, dx, lambda_dev, stream);
+}
+
+static int riemann_corrector(exa_dg_plan* p, double* u_dev, const double* trace_dev, const double* const* ghost_dev,
+                             const long* lo, const long* hi, double dt, const double* dx, double* lambda_dev, void* stream) {
     if (!p || !u_dev || !trace_dev || !dx) { set_error("exa_dg_riemann_corrector: NULL argument"); return EXA_ERR_INVALID; }
     StageBBox box;
+    box.lam = lambda_dev;
     CellBox cb;
     int rcb = make_box(p, lo, hi, &cb);
     if (rcb) return rcb;

@@ -1114,7 +1114,37 @@ struct StageBArgs {
     long lo[3], nb[3];     // box origin and extent
     const double* ghost[6];
     int tiled;             // box slots enumerated tile by tile (every nb[d] a multiple of the tile edge), else lexicographically
+    double* lam;           // CFL instantiations only: lam[0] = max(lam[0], largest eigenvalue of the corrected u over nodes and directions); zeroed by the caller
 };
+
+// r5: the CFL scan of the NEXT step inside the kernel that writes u (template flag CFL; the instantiation without it is the one every fixed-dt step
+// launches, unchanged).  The corrector update is element-wise (lane = one variable of one node, coalesced), the eigenvalue needs a node's whole state:
+// the new values pass through an LDS copy of the cell(s), one lane per node evaluates the eigenvalues, one integer atomic max per wave
+// (non-negative doubles order like their bit patterns; a NaN is kept: nan_max).  Replaces a pass of its own over u (dg_maxeig_kernel: 2 % of a step of
+// AderDgSolver.run at 128^3 cells, p = 5).
+template <int DIM, class PDE, int CPB, int NN, int NT>
+__device__ inline void stage_b_cfl_scan(const double* unode, long b0, long nbox, double* lam) {
+    constexpr int NV = PDE::NV;
+    const int tid = threadIdx.x;
+    double m = 0.0;
+    for (int nd = tid; nd < CPB * NN; nd += NT) {
+        if (b0 + nd / NN >= nbox) continue;
+        double q[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) q[v] = unode[nd * NV + v];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) m = nan_max(m, PDE::maxeig(q, d));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_xor(m, o, 64));
+    // one atomic per wave would be millions on ONE address (96 against 15 ms per 128^3 launch): the maximum only grows, so a wave whose value does not
+    // exceed what is there already (an L2-coherent read) has nothing to add -- after the first few workgroups almost every wave
+    if ((tid & 63) == 0) {
+        unsigned long long* lb = reinterpret_cast<unsigned long long*>(lam);
+        const unsigned long long mine = (unsigned long long)__double_as_longlong(m);
+        if (mine > __hip_atomic_load(lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(lb, mine);
+    }
+}
 #ifndef EXA_STAGE_B_TILE_SHIFT
 #define EXA_STAGE_B_TILE_SHIFT 3
 #endif
@@ -1124,13 +1154,14 @@ __host__ __device__ constexpr int pow2ceil(int x) { int p = 1; while (p < x) p <
 // Faces are laid out on aligned lane segments of GS = pow2ceil(Nf) lanes, 64/GS faces per wave pass:
 // the face-wide maximum eigenvalue (A.4) is a segmented butterfly of wavefront shuffles, no LDS, no
 // barrier; only the Rusanov fluxes go through LDS to reach the node-major corrector update.
-template <int DIM, int N, class PDE, int CPB, int NT>
+template <int DIM, int N, class PDE, int CPB, int NT, bool CFL = false>
 __global__ void __launch_bounds__(NT)
 dg_stage_b_kernel(double* __restrict__ u, const double* __restrict__ trace, StageBArgs A, long ncells, long nbox,
                   double dt, double idx0, double idx1, double idx2, DgOps<N> ops) {
     using G = Geo<DIM, N>;
     constexpr int NV = PDE::NV;
     constexpr int NN = G::NN, NF = G::NF;
+    __shared__ double unode[CFL ? CPB * NN * NV : 1];
     constexpr int NFACE = 2 * DIM;
     constexpr int TS = 2 * NV * NF;                     // doubles per (cell, d, side) trace
     constexpr int GS = pow2ceil(NF);                    // lanes per face segment
@@ -1255,19 +1286,25 @@ dg_stage_b_kernel(double* __restrict__ u, const double* __restrict__ trace, Stag
             un -= cR[d][i] * fR - cL[d][i] * fL;
         }
         u[cell * (NN * NV) + e] = un;
+        if constexpr (CFL) unode[task] = un;
+    }
+    if constexpr (CFL) {
+        __syncthreads();
+        stage_b_cfl_scan<DIM, PDE, CPB, NN, NT>(unode, b0, nbox, A.lam);
     }
 }
 
 // Dense variant for face sizes that are not a power of two (Nf = 9, 25, 36, 49): tasks (cell, face, node)
 // packed densely over the lanes, face-wide maximum through a small LDS array (a 36-node face on a 64-lane
 // segment would idle 44 % of the lanes of the trace loads).
-template <int DIM, int N, class PDE, int CPB, int NT>
+template <int DIM, int N, class PDE, int CPB, int NT, bool CFL = false>
 __global__ void __launch_bounds__(NT)
 dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace, StageBArgs A, long ncells, long nbox,
                   double dt, double idx0, double idx1, double idx2, DgOps<N> ops, PlainGeo geo) {
     using G = Geo<DIM, N>;
     constexpr int NV = PDE::NV;
     constexpr int NN = G::NN, NF = G::NF;
+    __shared__ double unode[CFL ? CPB * NN * NV : 1];
     constexpr int NFACE = 2 * DIM;
     constexpr int TS = 2 * NV * NF;                     // doubles per (cell, d, side) trace
     constexpr int KB = (CPB * NFACE * NF + NT - 1) / NT;
@@ -1418,6 +1455,11 @@ dg_stage_b_dense_kernel(double* __restrict__ u, const double* __restrict__ trace
             un -= cR[d][i] * fR - cL[d][i] * fL;
         }
         u[cell * (NN * NV) + e] = un;
+        if constexpr (CFL) unode[task] = un;
+    }
+    if constexpr (CFL) {
+        __syncthreads();
+        stage_b_cfl_scan<DIM, PDE, CPB, NN, NT>(unode, b0, nbox, A.lam);
     }
 }
 

@@ -35,6 +35,7 @@ int limiter_reconstruct(int dim, int N, int Ns, int nv, const double* patch, con
 struct StageBBox {
     long nc[3], lo[3], nb[3];
     const double* ghost[6];
+    double* lam = nullptr;      // not null: the CFL scan of the corrected u rides in the launch (exa_dg_riemann_corrector_cfl); the caller zeroes it
 };
 
 struct DgLaunchTable {

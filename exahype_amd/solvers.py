@@ -373,6 +373,7 @@ class AderDgSolver:
         # per sharded step.  None = off: the product path records nothing.
         self.stage_a_events = None
         self.exchange_events = None
+        self._cfl_out = None              # run(): 1-element tensor the step's stage B leaves the next CFL scan in (riemann_corrector(lam_out=))
         if part is not None and any(part.partitioned(d) for d in range(dim)):
             self.halo = HaloExchange(part, self.nc, self.ts, self.dev, stage_through_host=backend_is_gloo)
             # High priority: the pack copies and the RCCL transport kernels are dispatched ahead of the persistent interior launch, which
@@ -474,12 +475,23 @@ class AderDgSolver:
     def swap_traces(self):
         self.trace, self._trace2 = self._trace2, self.trace
 
-    def riemann_corrector(self, dt, lo=None, hi=None):
+    def riemann_corrector(self, dt, lo=None, hi=None, lam_out=None):
+        """Stage B on the box (default: the whole block).  lam_out (1-element float64 CUDA tensor): the launch also leaves the largest eigenvalue of
+        the corrected u there -- the next step's CFL scan without a pass of its own (exa_dg_riemann_corrector_cfl; not for term sets that see x, t)."""
         ghosts = self.halo.ghost_ptrs() if self.halo is not None else None
         self._where_and_when()
+        lo_, hi_ = (larr(lo) if lo is not None else None), (larr(hi) if hi is not None else None)
+        if lam_out is not None:
+            check(self.lib.exa_dg_riemann_corrector_cfl(self._plan, C.c_void_p(self._u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
+                                                        ghosts, lo_, hi_, dt, darr(self.dx), C.c_void_p(lam_out.data_ptr()), _stream_ptr()))
+            return
         check(self.lib.exa_dg_riemann_corrector(self._plan, C.c_void_p(self._u.data_ptr()), C.c_void_p(self.trace.data_ptr()),
-                                                ghosts, larr(lo) if lo is not None else None,
-                                                larr(hi) if hi is not None else None, dt, darr(self.dx), _stream_ptr()))
+                                                ghosts, lo_, hi_, dt, darr(self.dx), _stream_ptr()))
+
+    def can_fuse_cfl_scan(self):
+        """True where step() ends in a stage-B launch over the whole block that can carry the next CFL scan: the two-kernel step (sharded or not) of a
+        term set whose eigenvalue does not see x, t."""
+        return not (self._fused or self._one_kernel or _sees_position_and_time(self.lib, self.pde))
 
     def node_positions(self):
         """[n_cells * N^dim][3] physical coordinates of the nodes (CUDA, cached): origin + (cell + xi_i) dx"""
@@ -541,7 +553,7 @@ class AderDgSolver:
                 self._pending_dt = dt
                 return
             self.predictor_volume(dt)
-            self.riemann_corrector(dt)
+            self.riemann_corrector(dt, lam_out=self._cfl_out)
             return
         # (one-kernel step on a shard: the shell cells' kernel reads the ghosts the PREVIOUS step received -- complete, every step ends
         # with the wait for its exchange -- and is done before this step's exchange overwrites them; interior cells read no ghosts)
@@ -584,7 +596,7 @@ class AderDgSolver:
         if self._one_kernel:
             self._pending_dt = dt
         else:
-            self.riemann_corrector(dt)
+            self.riemann_corrector(dt, lam_out=self._cfl_out)
         if timed:
             self.exchange_events.append((ready, c0, c1, i0, i1, p1))
 
@@ -822,15 +834,24 @@ def _dg_run(self, t_end, cfl=0.4, max_steps=1000000):
     """Advance until `self.time` reaches t_end (as FVPatchGrid.run; r4 integrated a DURATION from a local t = 0 here) with the CFL step
     dt = cfl * min(dx) / ((2p+1) * d * lambda_max); with a partition the maximum eigenvalue is reduced over the ranks (the only true collective
     of the scheme).  Returns the number of steps; raises on a non-finite eigenvalue."""
-    steps = 0
-    while self.time < t_end * (1 - 1e-14) and steps < max_steps:
-        lam = self.max_eigenvalue()
-        if self.part is not None and self.part.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(lam, op=dist.ReduceOp.MAX)
-        dt = _cfl_step(float(lam[0]), cfl * min(self.dx) / ((2 * self.N - 1) * self.dim), t_end - self.time, "AderDgSolver.run")
-        self.step(dt)
-        steps += 1
+    torch = _torch()
+    steps, lam = 0, None
+    fuse = self.can_fuse_cfl_scan()        # r5: the scan of step n + 1 rides in stage B of step n (one pass over u per step less); the first step scans
+    try:
+        if fuse:
+            self._cfl_out = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        while self.time < t_end * (1 - 1e-14) and steps < max_steps:
+            if lam is None:
+                lam = self.max_eigenvalue()
+            if self.part is not None and self.part.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(lam, op=dist.ReduceOp.MAX)
+            dt = _cfl_step(float(lam[0]), cfl * min(self.dx) / ((2 * self.N - 1) * self.dim), t_end - self.time, "AderDgSolver.run")
+            self.step(dt)
+            lam = self._cfl_out if fuse else None
+            steps += 1
+    finally:
+        self._cfl_out = None
     return steps
 
 

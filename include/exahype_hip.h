@@ -198,6 +198,13 @@ int exa_dg_predictor_volume_box(exa_dg_plan* plan, double* u_dev, double* trace_
 int exa_dg_riemann_corrector(exa_dg_plan* plan, double* u_dev, const double* trace_dev,
                              const double* const* ghost_dev, const long* lo, const long* hi, double dt,
                              const double* dx, void* stream);
+/* The same launch with the CFL scan of the NEXT step riding in it: *lambda_dev (one double, device) receives the maximum of
+ * maxEigenvalue (`Unit test/Functions.h:3`) over the nodes of the box's corrected u and the directions -- what exa_dg_max_eigenvalue
+ * would return for those cells, without a pass of its own over u.  lambda_dev is set to zero on the stream first.  Term sets whose
+ * eigenvalue sees position / time (EXA_PDE_FLAG_XT) are refused: their scan needs the node coordinates (exa_pde_eval_device_at). */
+int exa_dg_riemann_corrector_cfl(exa_dg_plan* plan, double* u_dev, const double* trace_dev,
+                                 const double* const* ghost_dev, const long* lo, const long* hi, double dt,
+                                 const double* dx, double* lambda_dev, void* stream);
 /* Where and when: physical coordinates of the local block's origin (dim entries, NULL = 0) and the time at the start of the next
  * step.  Only term sets whose terms depend on position / time see them (pde_codegen.SympyPDE with flux(q, x, t, d) ...: the hooks
  * `Unit test/correctness_test.cpp:16-41` declares with (Q, x, h, t, dt)): stage A evaluates them at the nodes x = origin + (cell + xi_i) dx

@@ -150,6 +150,32 @@ def test_dg_cfl_time_loop():
     assert rel_err(s.download().reshape(-1), ref) < 1e-10
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,N,nc", [(2, 3, (3, 4)), (2, 4, (5, 2)), (3, 4, (2, 3, 2)), (3, 6, (3, 2, 2)), (3, 8, (2, 1, 2)), (3, 5, (1, 2, 2))])
+def test_stage_b_carries_the_next_cfl_scan(dim, N, nc):
+    """exa_dg_riemann_corrector_cfl: the launch that writes the corrected u also leaves its largest eigenvalue -- bit-equal to the separate scan
+    (exa_dg_max_eigenvalue) of the same u, and u itself bit-equal to the plain launch's; segmented and dense stage-B kernels, boxes with fewer cells than
+    a workgroup holds; a NaN in the state arrives as a NaN."""
+    import torch
+    from exahype_amd import solvers as exa
+    u = euler_dg_state(tuple(nc) + (N,) * dim, seed=50 + N)
+    a, b = exa.AderDgSolver(dim, N, nc, n_vars=5), exa.AderDgSolver(dim, N, nc, n_vars=5)
+    dt = 0.02 * min(a.dx) / (2 * N - 1)
+    lam = torch.full((1,), -1.0, dtype=torch.float64, device="cuda")
+    for s in (a, b):
+        s.upload(u)
+        s.predictor_volume(dt)
+    a.riemann_corrector(dt)
+    b.riemann_corrector(dt, lam_out=lam)
+    assert torch.equal(a.u, b.u)
+    assert float(lam[0]) == float(a.max_eigenvalue()[0]) > 0.0
+    b.u.reshape(-1)[7] = float("nan")                                       # (the corrected u of the next launch then holds a NaN)
+    b.predictor_volume(dt)
+    b.riemann_corrector(dt, lam_out=lam)
+    assert np.isnan(float(lam[0]))
+    assert a.can_fuse_cfl_scan()
+
+
 def test_cfl_step_rule():
     """dt = min(scale / lambda_max, time left); lambda_max == 0.0 exactly: one step to the end; NaN / inf / negative: the run has diverged and says so
     (r4 advice: fmax in the device reductions dropped a NaN and the loop went on with a finite lambda)."""
